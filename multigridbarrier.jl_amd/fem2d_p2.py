@@ -1,0 +1,395 @@
+"""2D simplicial P2(+bubble) discretization: mesh, operators, subdivision, AMG hierarchy.
+
+Setup-time data producer for BASELINE configs 2-3 (reference: src/fem2d_P2.jl).  The
+per-triangle node layout is the reference's
+``corner1, edge(1,2), corner2, edge(2,3), corner3, edge(3,1)[, centroid]``
+(reference: src/fem2d_P2.jl:19-20).
+
+The reference element tables (node matrix K, weights w, derivative matrices) are
+*derived* here from their definition -- the nodal basis of span{P2} (+) span{l1 l2 l3}
+on the 7 (or 6) nodes, differentiated along the barycentric directions (xi = l1,
+eta = l2 with corner3 at the origin), weights w_j = 2 * int phi_j -- in exact
+rational arithmetic.  `tests/test_setup.py` checks them against the values the
+reference tabulates (reference: src/fem2d_P2.jl:74-96, :109-128).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from fractions import Fraction
+from math import factorial
+from typing import Dict, List, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+from .amg_prolongators import amg_prolongations, amg_ruge_stuben
+from .blockmatrices import BlockDiag
+from .multigrid import (Geometry, MultiGrid, assemble_amg_dicts, assemble_amg_ladder,
+                        continuous_subspace, corner_labels_from_t, dedupe_labels,
+                        mask_dirichlet_rows)
+
+
+@dataclass
+class FEM2D_P2:
+    """Discretization descriptor (reference: src/fem2d_P2.jl:31-34)."""
+
+    bubble: bool
+    K: np.ndarray       # (3, N, 2) corner mesh
+    Kfull: np.ndarray   # (V, N, 2) full node mesh
+
+    dim = 2
+
+
+# ---------------------------------------------------------------------------
+# reference element
+# ---------------------------------------------------------------------------
+
+def _bary_nodes(bubble: bool):
+    h = Fraction(1, 2)
+    t = Fraction(1, 3)
+    nodes = [(1, 0, 0), (h, h, 0), (0, 1, 0), (0, h, h), (0, 0, 1), (h, 0, h)]
+    if bubble:
+        nodes.append((t, t, t))
+    return [tuple(Fraction(v) for v in nd) for nd in nodes]
+
+
+def _poly_mul(a, b):
+    out = {}
+    for (i, j), ca in a.items():
+        for (k, l), cb in b.items():
+            out[(i + k, j + l)] = out.get((i + k, j + l), 0) + ca * cb
+    return out
+
+
+def _poly_eval(p, x, y):
+    return sum(c * x ** i * y ** j for (i, j), c in p.items())
+
+
+def _poly_diff(p, axis):
+    out = {}
+    for (i, j), c in p.items():
+        if axis == 0 and i > 0:
+            out[(i - 1, j)] = out.get((i - 1, j), 0) + c * i
+        if axis == 1 and j > 0:
+            out[(i, j - 1)] = out.get((i, j - 1), 0) + c * j
+    return out
+
+
+def _poly_int(p):
+    """Integral over the unit reference triangle {x, y >= 0, x + y <= 1}."""
+    return sum(c * Fraction(factorial(i) * factorial(j), factorial(i + j + 2)) for (i, j), c in p.items())
+
+
+def _solve_exact(A, B):
+    n = len(A)
+    M = [list(A[i]) + list(B[i]) for i in range(n)]
+    for c in range(n):
+        piv = next(r for r in range(c, n) if M[r][c] != 0)
+        M[c], M[piv] = M[piv], M[c]
+        inv = 1 / M[c][c]
+        M[c] = [v * inv for v in M[c]]
+        for r in range(n):
+            if r != c and M[r][c] != 0:
+                f = M[r][c]
+                M[r] = [a - f * b for a, b in zip(M[r], M[c])]
+    return [row[n:] for row in M]
+
+
+_REF_CACHE: Dict[bool, dict] = {}
+
+
+def reference_triangle(bubble: bool = True) -> dict:
+    """K (V x 3), w (V), dx, dy (V x V) of the reference element, as float64 arrays
+    (reference: src/fem2d_P2.jl:74-96 and :109-128 tabulate the same quantities)."""
+    if bubble in _REF_CACHE:
+        return _REF_CACHE[bubble]
+    nodes = _bary_nodes(bubble)
+    V = len(nodes)
+    one = Fraction(1)
+    # reference coordinates: x = l1, y = l2, l3 = 1 - x - y
+    l1 = {(1, 0): one}
+    l2 = {(0, 1): one}
+    l3 = {(0, 0): one, (1, 0): -one, (0, 1): -one}
+    mons = [{(0, 0): one}, l1, l2, _poly_mul(l1, l1), _poly_mul(l1, l2), _poly_mul(l2, l2)]
+    if bubble:
+        mons.append(_poly_mul(_poly_mul(l1, l2), l3))
+    Vand = [[_poly_eval(m, nd[0], nd[1]) for m in mons] for nd in nodes]
+    eye = [[one if i == j else 0 * one for j in range(V)] for i in range(V)]
+    coef = _solve_exact(Vand, eye)            # coef[m][j]: coefficient of monomial m in phi_j
+    basis = []
+    for j in range(V):
+        pj = {}
+        for m in range(V):
+            for key, c in mons[m].items():
+                pj[key] = pj.get(key, 0) + coef[m][j] * c
+        basis.append(pj)
+    dx = np.array([[float(_poly_eval(_poly_diff(basis[j], 0), nd[0], nd[1])) for j in range(V)] for nd in nodes])
+    dy = np.array([[float(_poly_eval(_poly_diff(basis[j], 1), nd[0], nd[1])) for j in range(V)] for nd in nodes])
+    w = np.array([float(2 * _poly_int(basis[j])) for j in range(V)])
+    K = np.array([[float(v) for v in nd] for nd in nodes])
+    _REF_CACHE[bubble] = dict(K=K, w=w, dx=dx, dy=dy)
+    return _REF_CACHE[bubble]
+
+
+# child corner slots of the four red-refinement children, as parent local slots
+# (reference: src/fem2d_P2.jl:183-184: (ca,a,ab), (ab,b,bc), (bc,c,ca), (ab,bc,ca))
+_CHILD_CORNERS = ((5, 0, 1), (1, 2, 3), (3, 4, 5), (1, 3, 5))
+
+
+def _refine_p2_connectivity(t: np.ndarray) -> np.ndarray:
+    """Red-refine full P2(+bubble) connectivity (reference: src/fem2d_P2.jl:169-207).
+    Node ids are renumbered by first occurrence, child-edge nodes keyed by their
+    (sorted) endpoint pair, bubbles element-local."""
+    V, N = t.shape
+    out = np.empty((V, 4 * N), dtype=np.int64)
+    node_ids: Dict[int, int] = {}
+    for e in range(N):
+        for v in range(6):
+            i = int(t[v, e])
+            if i not in node_ids:
+                node_ids[i] = len(node_ids)
+    edge_nodes: Dict[Tuple[int, int], int] = {}
+    next_id = len(node_ids)
+    for e in range(N):
+        ids = [node_ids[int(t[v, e])] for v in range(6)]
+        for s, cc in enumerate(_CHILD_CORNERS):
+            j = 4 * e + s
+            corners = (ids[cc[0]], ids[cc[1]], ids[cc[2]])
+            out[0, j], out[2, j], out[4, j] = corners
+            for slot, u, v in ((1, corners[0], corners[1]), (3, corners[1], corners[2]), (5, corners[2], corners[0])):
+                key = (u, v) if u < v else (v, u)
+                eid = edge_nodes.get(key)
+                if eid is None:
+                    eid = next_id
+                    next_id += 1
+                    edge_nodes[key] = eid
+                out[slot, j] = eid
+            if V == 7:
+                out[6, j] = next_id
+                next_id += 1
+    return out
+
+
+def _default_Kfull(bubble: bool) -> np.ndarray:
+    """reference: src/fem2d_P2.jl:210-217 (two triangles on [-1,1]^2)."""
+    R = reference_triangle(bubble)
+    corners = np.array([[-1.0, -1], [1, -1], [-1, 1], [1, -1], [1, 1], [-1, 1]]).reshape(2, 3, 2)
+    Kf = np.einsum("vc,ecd->ved", R["K"], corners)   # (V, N, 2)
+    return Kf
+
+
+def _extract_corner_mesh(Kfull: np.ndarray) -> np.ndarray:
+    return Kfull[[0, 2, 4], :, :].copy()
+
+
+def _build_geometry(Kfull: np.ndarray, t: np.ndarray) -> Geometry:
+    """Fine-level isoparametric operators and weights (reference: src/fem2d_P2.jl:518-596)."""
+    p, N, _ = Kfull.shape
+    bubble = p == 7
+    R = reference_triangle(bubble)
+    Rdx, Rdy, Rw = R["dx"], R["dy"], R["w"]
+    X = Kfull[:, :, 0]            # (p, N)
+    Y = Kfull[:, :, 1]
+    x_xi, x_eta = Rdx @ X, Rdy @ X
+    y_xi, y_eta = Rdx @ Y, Rdy @ Y
+    detJ = x_xi * y_eta - x_eta * y_xi      # (p, N) at node j of element k
+    if not np.all(detJ > 0):
+        bad = np.argwhere(detJ.T <= 0)
+        raise ValueError(f"fem2d_P2: non-positive Jacobian at {len(bad)} node(s); "
+                         "supply orientation-preserving, non-self-intersecting elements")
+    invdet = 1.0 / detJ
+    # dx_block[j, m, k] = ( y_eta[j,k] Rdx[j,m] - y_xi[j,k] Rdy[j,m]) / detJ[j,k]
+    dxb = (y_eta * invdet)[:, None, :] * Rdx[:, :, None] - (y_xi * invdet)[:, None, :] * Rdy[:, :, None]
+    dyb = (-x_eta * invdet)[:, None, :] * Rdx[:, :, None] + (x_xi * invdet)[:, None, :] * Rdy[:, :, None]
+    idb = np.broadcast_to(np.eye(p)[:, :, None], (p, p, N)).copy()
+    w = (detJ * Rw[:, None]).T.reshape(-1)
+    ops = {"id": BlockDiag(idb), "dx": BlockDiag(dxb), "dy": BlockDiag(dyb)}
+    disc = FEM2D_P2(bubble, _extract_corner_mesh(Kfull), Kfull)
+    return Geometry(disc, np.asarray(t, dtype=np.int64), Kfull, w, ops)
+
+
+def fem2d_P2(bubble: bool | None = None, K: np.ndarray | None = None, t: np.ndarray | None = None) -> Geometry:
+    """Single-level P2(+bubble) geometry (reference: `fem2d_P2`, src/fem2d_P2.jl:262-277)."""
+    b = (K is None or K.shape[0] == 7) if bubble is None else bubble
+    Kf = _default_Kfull(b) if K is None else np.asarray(K, dtype=np.float64)
+    V = 7 if b else 6
+    if Kf.shape[0] != V:
+        raise ValueError(f"K must have {V} vertices per triangle for bubble={b}")
+    if Kf.shape[2] != 2:
+        raise ValueError("K must have spatial dim 2")
+    if t is None:
+        flat = Kf.transpose(1, 0, 2).reshape(-1, 2)
+        t = dedupe_labels(flat).reshape(Kf.shape[1], V).T
+    return _build_geometry(Kf, t)
+
+
+def subdivide(geom: Geometry, L: int) -> Geometry:
+    """`subdivide(geom, L)`: L-1 red refinements, fine geometry only (reference:
+    src/multigrid.jl:472 -> src/fem2d_P2.jl:468-596).
+
+    Child node coordinates are the parent element map evaluated at the child nodes.
+    For the straight-sided elements the package builds this is the affine image of
+    the child corners, identical (up to roundoff) to the reference's `refine * x`;
+    curved parents would need the reference's bubble-distribution table and are refused.
+    """
+    if not isinstance(geom.discretization, FEM2D_P2):
+        raise TypeError("subdivide: FEM2D_P2 geometry expected")
+    if L < 1:
+        raise ValueError("L must be >= 1")
+    Kf, t = geom.x, geom.t
+    p = Kf.shape[0]
+    RK = reference_triangle(p == 7)["K"]
+    straight = np.einsum("vc,ced->ved", RK, Kf[[0, 2, 4], :, :])
+    if not np.allclose(straight, Kf, rtol=0, atol=1e-13 * max(1.0, np.abs(Kf).max())):
+        raise NotImplementedError("subdivide: curved (isoparametric) P2 elements are not supported")
+    for _ in range(L - 1):
+        N = Kf.shape[1]
+        six = Kf[:6]                                       # (6, N, 2)
+        cc = np.array(_CHILD_CORNERS)                      # (4, 3)
+        child_corners = six[cc]                            # (4, 3, N, 2)
+        child_corners = child_corners.transpose(1, 2, 0, 3).reshape(3, 4 * N, 2)  # element-major, child fastest
+        Kf = np.einsum("vc,ced->ved", RK, child_corners)
+        t = _refine_p2_connectivity(t)
+    return _build_geometry(Kf, t)
+
+
+# ---------------------------------------------------------------------------
+# boundary + subspaces
+# ---------------------------------------------------------------------------
+
+def _p2_boundary_dedup_set(labels: np.ndarray, N: int) -> set:
+    """reference: src/fem2d_P2.jl:309-327 (half-edge use counts)."""
+    V = labels.size // N
+    t = labels.reshape(N, V)
+    a = t[:, [0, 1, 2, 3, 4, 5]].reshape(-1)
+    b = t[:, [1, 2, 3, 4, 5, 0]].reshape(-1)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    key = lo.astype(np.int64) * (int(labels.max()) + 1) + hi
+    uniq, counts = np.unique(key, return_counts=True)
+    once = uniq[counts == 1]
+    M = int(labels.max()) + 1
+    return set((once // M).tolist()) | set((once % M).tolist())
+
+
+def find_boundary(geom: Geometry) -> List[Tuple[int, int]]:
+    """(v, e) pairs (0-based) of P2 DOFs on the boundary (reference: src/fem2d_P2.jl:292-301)."""
+    V, N = geom.t.shape
+    labels = geom.labels
+    bset = _p2_boundary_dedup_set(labels, N)
+    isb = np.zeros(int(labels.max()) + 1, dtype=bool)
+    isb[list(bset)] = True
+    flat = np.nonzero(isb[labels])[0]
+    return [(int(i % V), int(i // V)) for i in flat]
+
+
+def _broken_p1_embedding(N: int, V: int) -> sp.csr_matrix:
+    """reference: src/fem2d_P2.jl:355-380."""
+    slot = np.array([[1, -1, 1], [1, 0, 0], [1, 1, -1], [0, 1, 0], [-1, 1, 1], [0, 0, 1]], dtype=float)
+    if V == 7:
+        slot = np.vstack([slot, np.full((1, 3), 1.0 / 3)])
+    blk = sp.csr_matrix(slot)
+    out = sp.kron(sp.identity(N, format="csr"), blk, format="csr")
+    out.eliminate_zeros()
+    return out
+
+
+def _extract_corners_and_connectivity(t: np.ndarray, x_fine: np.ndarray):
+    """reference: src/fem2d_P2.jl:608-624."""
+    V, N = t.shape
+    labels, n_v = corner_labels_from_t(t, (0, 2, 4))
+    tri_conn = labels.reshape(N, 3)
+    rows = (np.arange(N)[:, None] * V + np.array([0, 2, 4])[None, :]).reshape(-1)
+    corners = np.zeros((n_v, x_fine.shape[1]))
+    # first occurrence wins (any occurrence has the same coordinates up to roundoff)
+    _, first = np.unique(labels, return_index=True)
+    corners[labels[first]] = x_fine[rows[first]]
+    return corners, tri_conn
+
+
+def _assemble_p1_stiffness_full(corners: np.ndarray, tri_conn: np.ndarray) -> sp.csr_matrix:
+    """reference: src/fem2d_P2.jl:646-669."""
+    i1, i2, i3 = tri_conn[:, 0], tri_conn[:, 1], tri_conn[:, 2]
+    x1, y1 = corners[i1, 0], corners[i1, 1]
+    x2, y2 = corners[i2, 0], corners[i2, 1]
+    x3, y3 = corners[i3, 0], corners[i3, 1]
+    det2 = (x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1)
+    bs = np.stack([y2 - y3, y3 - y1, y1 - y2], axis=1)
+    cs = np.stack([x3 - x2, x1 - x3, x2 - x1], axis=1)
+    s = 1.0 / (2 * np.abs(det2))
+    vals = (bs[:, :, None] * bs[:, None, :] + cs[:, :, None] * cs[:, None, :]) * s[:, None, None]
+    rows = np.repeat(tri_conn[:, :, None], 3, axis=2)
+    cols = np.repeat(tri_conn[:, None, :], 3, axis=1)
+    n_v = corners.shape[0]
+    return sp.csr_matrix((vals.reshape(-1), (rows.reshape(-1), cols.reshape(-1))), shape=(n_v, n_v))
+
+
+def _interior_corners_to_doubled_p2(tri_conn: np.ndarray, n_v: int, interior_corners: np.ndarray, V: int) -> sp.csr_matrix:
+    """P1-corner -> broken P2(+bubble) bridge (reference: src/fem2d_P2.jl:675-708)."""
+    interior_idx = -np.ones(n_v, dtype=np.int64)
+    interior_idx[interior_corners] = np.arange(len(interior_corners))
+    N = tri_conn.shape[0]
+    ai, bi, ci = (interior_idx[tri_conn[:, k]] for k in range(3))
+    base = V * np.arange(N)
+    rows, cols, vals = [], [], []
+
+    def push(slot, col, val):
+        m = col >= 0
+        rows.append(base[m] + slot)
+        cols.append(col[m])
+        vals.append(np.full(int(m.sum()), val))
+
+    push(0, ai, 1.0); push(2, bi, 1.0); push(4, ci, 1.0)
+    push(1, ai, 0.5); push(1, bi, 0.5)
+    push(3, bi, 0.5); push(3, ci, 0.5)
+    push(5, ci, 0.5); push(5, ai, 0.5)
+    if V == 7:
+        for col in (ai, bi, ci):
+            push(6, col, 1.0 / 3)
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                         shape=(V * N, len(interior_corners)))
+
+
+def _hierarchy(tri_conn, K_full, interior, n_v, n_doubled, prolongator, V):
+    """reference: src/fem2d_P2.jl:388-398."""
+    interior = np.asarray(interior, dtype=np.int64)
+    K_loc = sp.csr_matrix(K_full)[interior][:, interior]
+    P_amg = amg_prolongations(K_loc, prolongator)
+    bridge = _interior_corners_to_doubled_p2(tri_conn, n_v, interior, V)
+    return assemble_amg_ladder(P_amg, bridge, n_doubled)
+
+
+def amg(geom: Geometry, prolongator=None, dirichlet_nodes: Dict[str, List[Tuple[int, int]]] | None = None) -> MultiGrid:
+    """AMG hierarchy on the continuous corners (reference: src/fem2d_P2.jl:400-455)."""
+    if prolongator is None:
+        prolongator = amg_ruge_stuben(max_coarse=2)
+    if dirichlet_nodes is None:
+        dirichlet_nodes = {"dirichlet": find_boundary(geom)}
+    x_fine = geom.xflat
+    V, N = geom.t.shape
+    n_doubled = V * N
+    full_labels = geom.labels
+    n_full_unique = int(full_labels.max()) + 1
+    corners, tri_conn = _extract_corners_and_connectivity(geom.t, x_fine)
+    n_v = corners.shape[0]
+    full_to_corner = -np.ones(n_full_unique, dtype=np.int64)
+    rows = (np.arange(N)[:, None] * V + np.array([0, 2, 4])[None, :]).reshape(-1)
+    full_to_corner[full_labels[rows]] = tri_conn.reshape(-1)
+    K_full = _assemble_p1_stiffness_full(corners, tri_conn)
+    refine_full, sizes_full, L_full, K_amg_full = _hierarchy(
+        tri_conn, K_full, np.arange(n_v), n_v, n_doubled, prolongator, V)
+
+    def build_dirichlet(nodes):
+        lin = np.array([v + e * V for (v, e) in nodes], dtype=np.int64)
+        dd_set = set(full_labels[lin].tolist())
+        dcorner = {int(full_to_corner[f]) for f in dd_set if full_to_corner[f] >= 0}
+        interior = np.array(sorted(set(range(n_v)) - dcorner), dtype=np.int64)
+        refine_dir, sizes_dir, L_dir, K_amg_dir = _hierarchy(
+            tri_conn, K_full, interior, n_v, n_doubled, prolongator, V)
+        refine_dir[K_amg_dir - 1] = mask_dirichlet_rows(refine_dir[K_amg_dir - 1], full_labels, dd_set)
+        sub = [sp.identity(sizes_dir[kk], format="csr") for kk in range(K_amg_dir)] + [None]
+        sub[L_dir - 1] = continuous_subspace(full_labels, n_full_unique, dd_set)
+        return refine_dir, sub
+
+    return assemble_amg_dicts(geom, n_doubled, dirichlet_nodes, refine_full, sizes_full, L_full,
+                              K_amg_full, build_dirichlet,
+                              full_riders={"broken_P1": _broken_p1_embedding(N, V)})
