@@ -1,0 +1,277 @@
+// api.cpp -- extern "C" surface of libmgbhip.so (include/mgbhip.h).  Every entry point
+// converts C++ exceptions to a status code + mgbhip_last_error(); nothing here computes on
+// the CPU: a missing / failing GPU is an error, never a fallback.
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+
+#include "problem.hpp"
+
+using namespace mgbhip;
+
+mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mgbhip_problem* share);
+int core_run(mgbhip_problem* P, double* z, const double* c, const mgbhip_options* opt, mgbhip_core_result* res);
+int matched_t_run(mgbhip_problem* P, const double* z, const double* c, double t_default, double* t_out);
+
+static thread_local std::string g_last_error;
+
+#define MGB_API_BEGIN try {
+#define MGB_API_END                                   \
+    }                                                 \
+    catch (const InvalidArgument& e) {                \
+        g_last_error = e.what();                      \
+        return MGBHIP_ERR_INVALID;                    \
+    }                                                 \
+    catch (const HipError& e) {                       \
+        g_last_error = e.what();                      \
+        return MGBHIP_ERR_HIP;                        \
+    }                                                 \
+    catch (const std::exception& e) {                 \
+        g_last_error = e.what();                      \
+        return MGBHIP_ERR_INVALID;                    \
+    }
+
+extern "C" {
+
+const char* mgbhip_last_error(void) { return g_last_error.c_str(); }
+const char* mgbhip_version(void) { return "mgbhip 0.1 (gfx950)"; }
+
+int mgbhip_create(mgbhip_ctx** out, int device_id, void* hip_stream) {
+    MGB_API_BEGIN
+    MGB_REQUIRE(out != nullptr, "null output pointer");
+    int count = 0;
+    MGB_HIP_CHECK(hipGetDeviceCount(&count));
+    MGB_REQUIRE(count > 0, "no HIP device visible: this library has no CPU fallback");
+    MGB_REQUIRE(device_id >= 0 && device_id < count, "device id out of range");
+    MGB_HIP_CHECK(hipSetDevice(device_id));
+    mgbhip_ctx* c = new mgbhip_ctx();
+    c->device = device_id;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        MGB_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    c->timers.stream = c->stream;
+    *out = c;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_destroy(mgbhip_ctx* ctx) {
+    MGB_API_BEGIN
+    if (!ctx) return MGBHIP_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->timers.reset(false);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* desc, mgbhip_problem* share,
+                          mgbhip_problem** out) {
+    MGB_API_BEGIN
+    MGB_REQUIRE(out != nullptr, "null output pointer");
+    *out = problem_create(ctx, desc, share);
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_problem_destroy(mgbhip_problem* prob) {
+    MGB_API_BEGIN
+    if (!prob) return MGBHIP_OK;
+    (void)hipStreamSynchronize(prob->stream());
+    delete prob;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_problem_set_box(mgbhip_problem* prob, double b, double R) {
+    MGB_API_BEGIN
+    MGB_REQUIRE(prob && prob->cone.feasibility, "set_box on a problem without the phase-I wrapper");
+    prob->cone.box_b = b;
+    prob->cone.box_R = R;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_problem_set_barrier_weights(mgbhip_problem* prob, const double* bw) {
+    MGB_API_BEGIN
+    MGB_REQUIRE(prob, "null problem");
+    if (bw) {
+        prob->bw.upload(bw, (size_t)prob->n, prob->stream());
+        MGB_HIP_CHECK(hipStreamSynchronize(prob->stream()));
+        prob->has_bw = true;
+    } else {
+        prob->has_bw = false;
+    }
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int64_t mgbhip_level_size(const mgbhip_problem* prob, int32_t level) {
+    if (!prob || level < 0 || level >= (int32_t)prob->levels.size()) return -1;
+    return prob->levels[level].m;
+}
+
+static void check_level(mgbhip_problem* P, int32_t level) {
+    MGB_REQUIRE(P != nullptr, "null problem");
+    MGB_REQUIRE(level >= 0 && level < (int32_t)P->levels.size(), "level out of range");
+}
+
+static void stage_inputs(mgbhip_problem* P, int32_t level, const double* s, const double* c, const double* z0) {
+    hipStream_t st = P->stream();
+    P->d_x.upload(s, (size_t)P->levels[level].m, st);
+    P->d_c.upload(c, (size_t)P->n * P->nD, st);
+    P->d_z0.upload(z0, (size_t)P->nu * P->n, st);
+}
+
+int mgbhip_f0(mgbhip_problem* P, int32_t level, const double* s, const double* c, const double* z0, double* value) {
+    MGB_API_BEGIN
+    check_level(P, level);
+    MGB_REQUIRE(s && c && z0 && value, "null argument");
+    stage_inputs(P, level, s, c, z0);
+    *value = P->eval_f0(level, P->d_x.p, P->d_z0.p, P->d_c.p);
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_f1(mgbhip_problem* P, int32_t level, const double* s, const double* c, const double* z0, double* grad) {
+    MGB_API_BEGIN
+    check_level(P, level);
+    MGB_REQUIRE(s && c && z0 && grad, "null argument");
+    stage_inputs(P, level, s, c, z0);
+    P->eval_f1(level, P->d_x.p, P->d_z0.p, P->d_c.p, P->d_g.p);
+    P->d_g.download(grad, (size_t)P->levels[level].m, P->stream());
+    MGB_HIP_CHECK(hipStreamSynchronize(P->stream()));
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_f2(mgbhip_problem* P, int32_t level, const double* s, const double* c, const double* z0, double* values) {
+    MGB_API_BEGIN
+    check_level(P, level);
+    MGB_REQUIRE(s && c && z0, "null argument");
+    stage_inputs(P, level, s, c, z0);
+    P->eval_f2(level, P->d_x.p, P->d_z0.p, P->d_c.p);
+    if (values) P->levels[level].Hval.download(values, (size_t)P->levels[level].nnz, P->stream());
+    MGB_HIP_CHECK(hipStreamSynchronize(P->stream()));
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_hessian_pattern(mgbhip_problem* P, int32_t level, int64_t* nnz, const int32_t** rowptr,
+                           const int32_t** colidx) {
+    MGB_API_BEGIN
+    check_level(P, level);
+    P->ensure_plan(level);
+    if (nnz) *nnz = P->levels[level].nnz;
+    if (rowptr) *rowptr = P->levels[level].hHptr.data();
+    if (colidx) *colidx = P->levels[level].hHcol.data();
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_solve(mgbhip_problem* P, int32_t level, const double* g, double* x) {
+    MGB_API_BEGIN
+    check_level(P, level);
+    MGB_REQUIRE(g && x, "null argument");
+    hipStream_t st = P->stream();
+    const size_t m = (size_t)P->levels[level].m;
+    P->d_g.upload(g, m, st);
+    P->factor(level);
+    P->trisolve(level, P->d_g.p, P->d_nv.p);
+    const int status = P->levels[level].solver.status(st);
+    P->d_nv.download(x, m, st);
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (status != MGBHIP_OK) g_last_error = "Cholesky met a non-positive pivot";
+    return status;
+    MGB_API_END
+}
+
+static int node_map(mgbhip_problem* P, const double* z, double* F, double* Dz, int mode) {
+    MGB_REQUIRE(P && z && F, "null argument");
+    hipStream_t st = P->stream();
+    P->d_z0.upload(z, (size_t)P->nu * P->n, st);
+    ElemParams E = P->base_params(-1, nullptr, P->d_z0.p, nullptr);
+    if (Dz) {
+        P->d_nodeDz.ensure((size_t)P->n * P->nD);
+        E.out_Dz = P->d_nodeDz.p;
+    }
+    launch_elem(E, mode, st);
+    P->d_nodeF.download(F, (size_t)P->n, st);
+    if (Dz) P->d_nodeDz.download(Dz, (size_t)P->n * P->nD, st);
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    return MGBHIP_OK;
+}
+
+int mgbhip_node_barrier(mgbhip_problem* P, const double* z, double* F, double* Dz) {
+    MGB_API_BEGIN
+    return node_map(P, z, F, Dz, MODE_NODE_F);
+    MGB_API_END
+}
+
+int mgbhip_node_slack(mgbhip_problem* P, const double* z, double* slack) {
+    MGB_API_BEGIN
+    return node_map(P, z, slack, nullptr, MODE_NODE_SLACK);
+    MGB_API_END
+}
+
+void mgbhip_default_options(mgbhip_options* o, int64_t n_nodes) {
+    const double eps = std::numeric_limits<double>::epsilon();
+    o->tol = std::sqrt(eps);
+    o->t = 0.1;
+    o->kappa = 10.0;
+    o->maxit = 10000;
+    o->max_newton = (int32_t)std::ceil(std::log2(-std::log2(eps)) + 2);
+    o->ls_beta = 0.5;
+    o->ls_c1 = 0.1;
+    o->line_search = 0;
+    o->stop_lambda_tol = 0.25 / std::sqrt((double)n_nodes);
+    o->stop_theta = 0.9;
+    o->finalize = 1;
+    o->finalize_theta = 0.9;
+    o->early_stop = 0;
+}
+
+int mgbhip_mgb_core(mgbhip_problem* P, double* z, const double* c, const mgbhip_options* opt, mgbhip_core_result* res) {
+    MGB_API_BEGIN
+    MGB_REQUIRE(P && z && c && opt && res, "null argument");
+    MGB_REQUIRE(opt->tol > 0 && opt->t > 0 && opt->kappa > 1 && opt->maxit >= 1 && opt->max_newton >= 1, "bad options");
+    int rc = core_run(P, z, c, opt, res);
+    if (rc == MGBHIP_ERR_CONVERGENCE)
+        g_last_error = res->failure_code == 2 ? "Convergence failure in mgb_solve: iteration_limit"
+                                              : "Convergence failure in mgb_solve: stall";
+    return rc;
+    MGB_API_END
+}
+
+int mgbhip_matched_t(mgbhip_problem* P, const double* z, const double* c, double t_default, double* t_out) {
+    MGB_API_BEGIN
+    MGB_REQUIRE(P && z && c && t_out, "null argument");
+    return matched_t_run(P, z, c, t_default, t_out);
+    MGB_API_END
+}
+
+int mgbhip_stage_ms(mgbhip_problem* P, const char* stage, double* total_ms, int64_t* launches) {
+    MGB_API_BEGIN
+    MGB_REQUIRE(P && stage, "null argument");
+    P->ctx->timers.collect();
+    auto it = P->ctx->timers.recs.find(stage);
+    if (total_ms) *total_ms = it == P->ctx->timers.recs.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == P->ctx->timers.recs.end() ? 0 : it->second.launches;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_reset_stage_timers(mgbhip_problem* P, int enable) {
+    MGB_API_BEGIN
+    MGB_REQUIRE(P, "null argument");
+    P->ctx->timers.reset(enable != 0);
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+}  // extern "C"

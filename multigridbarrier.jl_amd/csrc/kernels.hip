@@ -1,0 +1,554 @@
+// kernels.hip -- evaluate / assemble kernels of the barrier functional on gfx950.
+//
+// One fused element kernel family replaces the reference's chain
+//   R*s (SpMV) -> apply_D (nD block matvecs) -> map_rows_gpu(F) -> D' back-multiplies ->
+//   16 fused triple products + _hess_add! temporaries
+// (reference: src/convex.jl:155-202, src/BlockMatrices.jl:170-188, :604-640; CUDA twins
+// ext/MultiGridBarrierCUDAExt/block_ops.jl:31-148, map_rows_gpu.jl:20-28): a group of
+// G = 2^ceil(log2 p) lanes owns one element, lane r owns node r.  The element's operator
+// blocks are staged through LDS with a flat coalesced copy (they are contiguous in the
+// reference's p x p x N layout), Dz, the cone functor and the per-element 14x14 (nu*p)
+// Hessian block never leave the CU.  HBM traffic is the compulsory one of SURVEY.md
+// section 8(d): operators + z + grids in, element blocks out.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+
+#include "kernels.hpp"
+
+namespace mgbhip {
+
+namespace {
+
+__device__ __forceinline__ int tri_index(int k, int k2, int NY) {   // k <= k2
+    return k * NY - (k * (k - 1)) / 2 + (k2 - k);
+}
+
+template <int NY, int MODE>
+__global__ __launch_bounds__(256) void elem_kernel(const ElemParams P, const int lgG) {
+    extern __shared__ double sh[];
+    const int tid = threadIdx.x;
+    const int G = 1 << lgG;
+    const int EPB = 256 >> lgG;
+    const int el = tid >> lgG;
+    const int r = tid & (G - 1);
+    const int p = P.p;
+    const int pp = p * p;
+    const int nu = P.nu;
+    const int64_t e = (int64_t)blockIdx.x * EPB + el;
+    const bool active = (e < P.N) && (r < p);
+    const int64_t n = P.n;
+    const int64_t node = e * p + r;
+
+    double* zl = sh;                                    // [EPB][nu][G]
+    double* opL = zl + 256 * nu;                        // [nstage][EPB][pp]
+    double* YL = opL + (size_t)P.nstage * EPB * pp;     // MODE_F1: [EPB][NY][G]; MODE_F2: [EPB][tri][G]
+
+    // 1. stage the operator blocks of this workgroup's elements (flat, coalesced)
+    {
+        const int64_t e0 = (int64_t)blockIdx.x * EPB;
+        int64_t lim = (P.N - e0) * pp;
+        if (lim > (int64_t)EPB * pp) lim = (int64_t)EPB * pp;
+        for (int o = 0; o < P.nstage; ++o) {
+            const double* src = P.stage_ptr[o] + e0 * pp;
+            double* dst = opL + (size_t)o * EPB * pp;
+            for (int i = tid; i < lim; i += 256) dst[i] = src[i];
+        }
+    }
+    // 2. fine broken-basis values of this element: z0 + R*s  (src/convex.jl:156)
+    if (active) {
+        for (int a = 0; a < nu; ++a) {
+            const int64_t row = (int64_t)a * n + node;
+            double v = P.z0[row];
+            if (P.s != nullptr) {
+                for (int32_t q = P.Rptr[row]; q < P.Rptr[row + 1]; ++q) v += P.Rval[q] * P.s[P.Rcol[q]];
+            }
+            zl[(el * nu + a) * G + r] = v;
+        }
+    }
+    __syncthreads();
+
+    auto OP = [&](int k, int rr, int cc) -> double {    // D_k block entry (rr, cc) of this element
+        const int so = P.D_stage[k];
+        if (so >= 0) return opL[((size_t)so * EPB + el) * pp + cc * p + rr];
+        return P.ops[P.D_op[k]][e * pp + cc * p + rr];
+    };
+
+    // 3. Dz at this node (src/convex.jl:125)
+    double y[NY];
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+        double v = 0.0;
+        if (active) {
+            const int a = P.D_state[k];
+            if (P.D_stage[k] == -1) {
+                v = zl[(el * nu + a) * G + r];
+            } else {
+                for (int cc = 0; cc < p; ++cc) v += OP(k, r, cc) * zl[(el * nu + a) * G + cc];
+            }
+        }
+        y[k] = v;
+    }
+
+    double F = 0.0;
+    double g[NY];
+    double H[NY * NY];
+    (void)g;
+    (void)H;
+
+    if (MODE == MODE_F0 || MODE == MODE_NODE_F) {
+        if (active) cone_eval<NY, 0>(P.cone, node, n, y, F, g, H);
+        if (MODE == MODE_NODE_F) {
+            if (active) {
+                P.out_F[node] = F;
+                if (P.out_Dz != nullptr) {
+#pragma unroll
+                    for (int k = 0; k < NY; ++k) P.out_Dz[node + n * k] = y[k];
+                }
+            }
+            return;
+        }
+        double val = 0.0;
+        if (active) {
+            double bar;
+            if (P.bw != nullptr) {
+                const double bwv = P.bw[node];
+                bar = (bwv == 0.0) ? 0.0 : bwv * F;
+            } else {
+                bar = P.invn * F;
+            }
+            double lin = 0.0;
+#pragma unroll
+            for (int k = 0; k < NY; ++k) lin += P.c[node + n * k] * y[k];
+            val = bar + P.w[node] * lin;
+        }
+        __syncthreads();            // zl / opL no longer needed: reuse LDS for the reduction
+        sh[tid] = val;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) sh[tid] += sh[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) P.out_partial[blockIdx.x] = sh[0];
+        return;
+    }
+    if (MODE == MODE_NODE_SLACK) {
+        if (active) P.out_F[node] = cone_slack<NY>(P.cone, node, n, y);
+        return;
+    }
+    if (MODE == MODE_F1) {
+        // Y = scale(grad F) + w .* c   (src/convex.jl:170-173), then sum_k D_k' Y_k per element
+        if (active) {
+            cone_eval<NY, 1>(P.cone, node, n, y, F, g, H);
+            const double wv = P.w[node];
+            const double bwv = P.bw ? P.bw[node] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NY; ++k) {
+                double sc = P.bw ? ((bwv == 0.0) ? 0.0 : bwv * g[k]) : P.invn * g[k];
+                YL[(el * NY + k) * G + r] = sc + wv * P.c[node + n * k];
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const int i = r;
+            for (int a = 0; a < nu; ++a) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NY; ++k) {
+                    if (P.D_state[k] != a) continue;
+                    const double* Yk = YL + (el * NY + k) * G;
+                    if (P.D_stage[k] == -1) {
+                        acc += Yk[i];
+                    } else {
+                        for (int rr = 0; rr < p; ++rr) acc += OP(k, rr, i) * Yk[rr];
+                    }
+                }
+                P.out_ret[(int64_t)a * n + node] = acc;
+            }
+        }
+        return;
+    }
+    if (MODE == MODE_F2) {
+        constexpr int NT = NY * (NY + 1) / 2;
+        if (active) {
+            cone_eval<NY, 2>(P.cone, node, n, y, F, g, H);
+            const double bwv = P.bw ? P.bw[node] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NY; ++k)
+#pragma unroll
+                for (int k2 = k; k2 < NY; ++k2) {
+                    const double h = H[k * NY + k2];
+                    const double sc = P.bw ? ((bwv == 0.0) ? 0.0 : bwv * h) : P.invn * h;
+                    YL[((size_t)el * NT + tri_index(k, k2, NY)) * G + r] = sc;
+                }
+        }
+        __syncthreads();
+        if (active) {
+            // lane j = r owns column j of every block (a,b), a <= b, of the element Hessian
+            //   Hel_ab[i,j] = sum_rr sum_{k in K_a} sum_{k2 in K_b} D_k[rr,i] Y[rr][k,k2] D_k2[rr,j]
+            // (src/convex.jl:191-200 with the 16 temporaries fused away)
+            const int j = r;
+            const int NB = nu * (nu + 1) / 2;
+            for (int a = 0; a < nu; ++a)
+                for (int b = a; b < nu; ++b) {
+                    const int blk = a * nu - (a * (a - 1)) / 2 + (b - a);
+                    double* out = P.out_hel + ((e * NB + blk) * p + j) * (int64_t)p;
+                    for (int i = 0; i < p; ++i) {
+                        double val = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NY; ++k) {
+                            if (P.D_state[k] != a) continue;
+                            const bool idk = P.D_stage[k] == -1;
+#pragma unroll
+                            for (int k2 = 0; k2 < NY; ++k2) {
+                                if (P.D_state[k2] != b) continue;
+                                const bool idk2 = P.D_stage[k2] == -1;
+                                const int t = (k <= k2) ? tri_index(k, k2, NY) : tri_index(k2, k, NY);
+                                const double* Yt = YL + ((size_t)el * NT + t) * G;
+                                if (idk && idk2) {
+                                    val += (i == j) ? Yt[i] : 0.0;
+                                } else if (idk) {
+                                    val += Yt[i] * OP(k2, i, j);
+                                } else if (idk2) {
+                                    val += OP(k, j, i) * Yt[j];
+                                } else {
+                                    double acc = 0.0;
+                                    for (int rr = 0; rr < p; ++rr) acc += OP(k, rr, i) * Yt[rr] * OP(k2, rr, j);
+                                    val += acc;
+                                }
+                            }
+                        }
+                        out[i] = val;
+                    }
+                }
+        }
+        return;
+    }
+}
+
+// ---- reductions ------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t count,
+                                                              double* __restrict__ out) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int64_t i = tid; i < count; i += 256) s += partials[i];
+    red[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = red[0];
+}
+
+// MODE 0: sum a*b ; MODE 1: sum a*a and count of non-finite a
+template <int MODE>
+__global__ __launch_bounds__(256) void block_reduce_kernel(const double* __restrict__ a, const double* __restrict__ b,
+                                                           int64_t n, double* __restrict__ partials) {
+    __shared__ double red[256];
+    __shared__ double red2[256];
+    const int tid = threadIdx.x;
+    double s = 0.0, bad = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = a[i];
+        if (MODE == 0) s += v * b[i];
+        else {
+            s += v * v;
+            bad += isfinite(v) ? 0.0 : 1.0;
+        }
+    }
+    red[tid] = s;
+    red2[tid] = bad;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) { red[tid] += red[tid + off]; red2[tid] += red2[tid + off]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        partials[blockIdx.x] = red[0];
+        if (MODE == 1) partials[gridDim.x + blockIdx.x] = red2[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce2_kernel(const double* __restrict__ partials, int nb,
+                                                      double* __restrict__ out, int nout) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    for (int o = 0; o < nout; ++o) {
+        double s = 0.0;
+        for (int i = tid; i < nb; i += 256) s += partials[o * nb + i];
+        red[tid] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) red[tid] += red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) out[o] = red[0];
+        __syncthreads();
+    }
+}
+
+// ---- sparse matvecs ------------------------------------------------------------------------------
+
+template <bool ADD>
+__global__ __launch_bounds__(256) void csr_matvec_row_kernel(int64_t rows, const int32_t* __restrict__ ptr,
+                                                             const int32_t* __restrict__ col,
+                                                             const double* __restrict__ val,
+                                                             const double* __restrict__ x, double* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    double s = 0.0;
+    for (int32_t q = ptr[i]; q < ptr[i + 1]; ++q) s += val[q] * x[col[q]];
+    y[i] = ADD ? y[i] + s : s;
+}
+
+template <bool ADD>
+__global__ __launch_bounds__(256) void csr_matvec_wave_kernel(int64_t rows, const int32_t* __restrict__ ptr,
+                                                              const int32_t* __restrict__ col,
+                                                              const double* __restrict__ val,
+                                                              const double* __restrict__ x, double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    double s = 0.0;
+    for (int32_t q = ptr[i] + lane; q < ptr[i + 1]; q += 64) s += val[q] * x[col[q]];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) y[i] = ADD ? y[i] + s : s;
+}
+
+__global__ __launch_bounds__(256) void step_kernel(const double* __restrict__ x, const double* __restrict__ nn,
+                                                   double s, double* __restrict__ xn, int64_t len,
+                                                   int32_t* __restrict__ moved) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool m = false;
+    if (i < len) {
+        const double xi = x[i];
+        const double v = xi - s * nn[i];
+        xn[i] = v;
+        m = (v != xi);
+    }
+    if (__any(m) && (threadIdx.x & 63) == 0) atomicOr(moved, 1);
+}
+
+__global__ __launch_bounds__(256) void scale_copy_kernel(const double* __restrict__ src, double alpha,
+                                                         double* __restrict__ dst, int64_t len) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < len) dst[i] = alpha * src[i];
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(double alpha, const double* __restrict__ x,
+                                                   double* __restrict__ y, int64_t len) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < len) y[i] += alpha * x[i];
+}
+
+// ---- assembly ------------------------------------------------------------------------------------
+
+// Row-owner gather: every structural nonzero of R'HR sums its contributions from the
+// element-block slab in a fixed order -- no atomics (the reference's CUDA path uses fp64
+// atomics, ext/MultiGridBarrierCUDAExt/block_ops.jl:229-249).
+__global__ __launch_bounds__(256) void gather_assemble_kernel(int64_t nnz, const int32_t* __restrict__ cptr,
+                                                              const int32_t* __restrict__ cidx,
+                                                              const double* __restrict__ slab,
+                                                              double* __restrict__ Hval) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nnz) return;
+    double s = 0.0;
+    for (int32_t t = cptr[q]; t < cptr[q + 1]; ++t) s += slab[cidx[t]];
+    Hval[q] = s;
+}
+
+// General (coarse) levels: one workgroup per element; thread (ia, ib) computes
+// panel_a[:, ia]' * Hel_ab * panel_b[:, ib] and adds it into H (binary search in the CSR row).
+__global__ __launch_bounds__(256) void panel_assemble_kernel(const PanelParams P) {
+    const int64_t e = blockIdx.x;
+    const int p = P.p, nu = P.nu;
+    const int NB = nu * (nu + 1) / 2;
+    const int tid = threadIdx.x;
+    for (int a = 0; a < nu; ++a) {
+        const int32_t oa = P.ecol_ptr[e * nu + a], ca = P.ecol_ptr[e * nu + a + 1] - oa;
+        const double* pa = P.panels + (int64_t)p * oa;
+        for (int b = 0; b < nu; ++b) {
+            const int32_t ob = P.ecol_ptr[e * nu + b], cb = P.ecol_ptr[e * nu + b + 1] - ob;
+            const double* pb = P.panels + (int64_t)p * ob;
+            const bool tr = a > b;
+            const int blk = tr ? (b * nu - (b * (b - 1)) / 2 + (a - b)) : (a * nu - (a * (a - 1)) / 2 + (b - a));
+            const double* Hb = P.hel + (e * NB + blk) * (int64_t)p * p;
+            for (int t = tid; t < ca * cb; t += 256) {
+                const int ia = t % ca, ib = t / ca;
+                double acc = 0.0;
+                for (int ss = 0; ss < p; ++ss) {
+                    const double pbv = pb[ss + p * ib];
+                    if (pbv == 0.0) continue;
+                    double inner = 0.0;
+                    for (int rr = 0; rr < p; ++rr) {
+                        const double h = tr ? Hb[ss + p * rr] : Hb[rr + p * ss];
+                        inner += pa[rr + p * ia] * h;
+                    }
+                    acc += inner * pbv;
+                }
+                const int32_t row = P.ecols[oa + ia], colv = P.ecols[ob + ib];
+                int32_t lo = P.Hptr[row], hi = P.Hptr[row + 1] - 1;
+                while (lo < hi) {
+                    const int32_t mid = (lo + hi) >> 1;
+                    if (P.Hcol[mid] < colv) lo = mid + 1;
+                    else hi = mid;
+                }
+                unsafeAtomicAdd(&P.Hval[lo], acc);
+            }
+        }
+    }
+}
+
+template <int NY>
+void launch_elem_ny(const ElemParams& P, int mode, int lgG, dim3 grid, size_t lds, hipStream_t st) {
+    switch (mode) {
+        case MODE_F0: hipLaunchKernelGGL((elem_kernel<NY, MODE_F0>), grid, dim3(256), lds, st, P, lgG); break;
+        case MODE_F1: hipLaunchKernelGGL((elem_kernel<NY, MODE_F1>), grid, dim3(256), lds, st, P, lgG); break;
+        case MODE_F2: hipLaunchKernelGGL((elem_kernel<NY, MODE_F2>), grid, dim3(256), lds, st, P, lgG); break;
+        case MODE_NODE_F: hipLaunchKernelGGL((elem_kernel<NY, MODE_NODE_F>), grid, dim3(256), lds, st, P, lgG); break;
+        case MODE_NODE_SLACK: hipLaunchKernelGGL((elem_kernel<NY, MODE_NODE_SLACK>), grid, dim3(256), lds, st, P, lgG); break;
+        default: throw InvalidArgument("launch_elem: bad mode");
+    }
+}
+
+template <int NY>
+void set_lds_attr() {
+    const int big = 160 * 1024;
+    (void)hipFuncSetAttribute((const void*)elem_kernel<NY, MODE_F0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)elem_kernel<NY, MODE_F1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)elem_kernel<NY, MODE_F2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)elem_kernel<NY, MODE_NODE_F>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)elem_kernel<NY, MODE_NODE_SLACK>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipGetLastError();
+}
+
+}  // namespace
+
+int elem_group(int p) {
+    int g = 1;
+    while (g < p) g <<= 1;
+    return g < 2 ? 2 : g;
+}
+
+int64_t elem_grid(int p, int64_t N) {
+    const int epb = 256 / elem_group(p);
+    return (N + epb - 1) / epb;
+}
+
+size_t elem_lds_bytes(const ElemParams& P, int mode) {
+    const int G = elem_group(P.p);
+    const int EPB = 256 / G;
+    size_t d = 256 * (size_t)P.nu + (size_t)P.nstage * EPB * P.p * P.p;
+    if (mode == MODE_F1) d += 256 * (size_t)P.nD;
+    if (mode == MODE_F2) d += 256 * (size_t)(P.nD * (P.nD + 1) / 2);
+    if (d < 256) d = 256;
+    return d * sizeof(double);
+}
+
+void launch_elem(const ElemParams& P, int mode, hipStream_t st) {
+    MGB_REQUIRE(P.p >= 1 && P.p <= 64, "element kernels support 1 <= p <= 64 nodes per element");
+    MGB_REQUIRE(P.nD >= 1 && P.nD <= MGBHIP_MAX_ND, "nD out of range");
+    static std::once_flag once;
+    std::call_once(once, [] {
+        set_lds_attr<1>(); set_lds_attr<2>(); set_lds_attr<3>(); set_lds_attr<4>();
+        set_lds_attr<5>(); set_lds_attr<6>(); set_lds_attr<7>(); set_lds_attr<8>();
+    });
+    const int G = elem_group(P.p);
+    int lgG = 0;
+    while ((1 << lgG) < G) ++lgG;
+    const dim3 grid((unsigned)elem_grid(P.p, P.N));
+    const size_t lds = elem_lds_bytes(P, mode);
+    MGB_REQUIRE(lds <= 160 * 1024, "element kernel LDS budget exceeded");
+    switch (P.nD) {
+        case 1: launch_elem_ny<1>(P, mode, lgG, grid, lds, st); break;
+        case 2: launch_elem_ny<2>(P, mode, lgG, grid, lds, st); break;
+        case 3: launch_elem_ny<3>(P, mode, lgG, grid, lds, st); break;
+        case 4: launch_elem_ny<4>(P, mode, lgG, grid, lds, st); break;
+        case 5: launch_elem_ny<5>(P, mode, lgG, grid, lds, st); break;
+        case 6: launch_elem_ny<6>(P, mode, lgG, grid, lds, st); break;
+        case 7: launch_elem_ny<7>(P, mode, lgG, grid, lds, st); break;
+        case 8: launch_elem_ny<8>(P, mode, lgG, grid, lds, st); break;
+    }
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_reduce_partials(const double* partials, int64_t count, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, partials, count, out);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+static int reduce_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int64_t reduce_scratch_doubles(int64_t n) { return 2 * (int64_t)reduce_blocks(n); }
+
+void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st) {
+    const int nb = reduce_blocks(n);
+    hipLaunchKernelGGL(block_reduce_kernel<1>, dim3(nb), dim3(256), 0, st, v, (const double*)nullptr, n, scratch);
+    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats, 2);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_dot(const double* a, const double* b, int64_t n, double* scratch, double* out, hipStream_t st) {
+    const int nb = reduce_blocks(n);
+    hipLaunchKernelGGL(block_reduce_kernel<0>, dim3(nb), dim3(256), 0, st, a, b, n, scratch);
+    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, out, 1);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_csr_matvec(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val,
+                       const double* x, double* y, bool add, bool long_rows, hipStream_t st) {
+    if (rows == 0) return;
+    if (long_rows) {
+        const dim3 grid((unsigned)((rows + 3) / 4));
+        if (add) hipLaunchKernelGGL(csr_matvec_wave_kernel<true>, grid, dim3(256), 0, st, rows, ptr, col, val, x, y);
+        else hipLaunchKernelGGL(csr_matvec_wave_kernel<false>, grid, dim3(256), 0, st, rows, ptr, col, val, x, y);
+    } else {
+        const dim3 grid((unsigned)((rows + 255) / 256));
+        if (add) hipLaunchKernelGGL(csr_matvec_row_kernel<true>, grid, dim3(256), 0, st, rows, ptr, col, val, x, y);
+        else hipLaunchKernelGGL(csr_matvec_row_kernel<false>, grid, dim3(256), 0, st, rows, ptr, col, val, x, y);
+    }
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_step(const double* x, const double* n, double s, double* xn, int64_t len, int32_t* moved,
+                 hipStream_t st) {
+    if (len == 0) return;
+    hipLaunchKernelGGL(step_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, x, n, s, xn, len, moved);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_scale_copy(const double* src, double alpha, double* dst, int64_t len, hipStream_t st) {
+    if (len == 0) return;
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, src, alpha, dst, len);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_axpy(double alpha, const double* x, double* y, int64_t len, hipStream_t st) {
+    if (len == 0) return;
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, alpha, x, y, len);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,
+                            double* Hval, hipStream_t st) {
+    if (nnz == 0) return;
+    hipLaunchKernelGGL(gather_assemble_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, cptr, cidx,
+                       slab, Hval);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_panel_assemble(const PanelParams& P, hipStream_t st) {
+    if (P.N == 0) return;
+    hipLaunchKernelGGL(panel_assemble_kernel, dim3((unsigned)P.N), dim3(256), 0, st, P);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace mgbhip

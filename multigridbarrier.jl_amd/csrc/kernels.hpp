@@ -1,0 +1,79 @@
+// kernels.hpp -- launch wrappers of the evaluate/assemble kernels (kernels.hip).
+#pragma once
+#include "common.hpp"
+#include "cone.hpp"
+
+namespace mgbhip {
+
+enum ElemMode { MODE_F0 = 0, MODE_F1 = 1, MODE_F2 = 2, MODE_NODE_F = 3, MODE_NODE_SLACK = 4 };
+
+struct ElemParams {
+    int32_t p, nu, nD, nstage;
+    int64_t N, n;
+    const double* ops[MGBHIP_MAX_OPS];       // device operator arrays (nullptr = identity)
+    const double* stage_ptr[MGBHIP_MAX_OPS]; // operators staged through LDS (distinct, non-identity)
+    int32_t D_state[MGBHIP_MAX_ND];
+    int32_t D_op[MGBHIP_MAX_ND];             // index into ops
+    int32_t D_stage[MGBHIP_MAX_ND];          // -1 identity, >= 0 slot in stage_ptr, -2 read from HBM
+    const double* w;
+    const double* c;                         // n x nD (may be nullptr for the node maps)
+    const double* z0;                        // nu*n
+    const double* s;                         // m_J or nullptr
+    const int32_t* Rptr;
+    const int32_t* Rcol;
+    const double* Rval;
+    const double* bw;                        // barrier weights or nullptr
+    double invn;
+    ConeDev cone;
+    double* out_partial;                     // f0: one partial per workgroup
+    double* out_ret;                         // f1: nu*n vector sum_k D_k' Y_k
+    double* out_hel;                         // f2: element Hessian blocks
+    double* out_F;                           // node maps
+    double* out_Dz;
+};
+
+// element Hessian slab layout: per element, blocks (a,b), a <= b, in row-major order of
+// the upper block triangle, each p x p column-major.
+inline int hel_blocks(int nu) { return nu * (nu + 1) / 2; }
+inline int hel_block_index(int a, int b, int nu) { return a * nu - a * (a - 1) / 2 + (b - a); }
+
+int elem_group(int p);                                   // lanes per element (power of two >= p)
+int64_t elem_grid(int p, int64_t N);                     // workgroups
+size_t elem_lds_bytes(const ElemParams& P, int mode);
+void launch_elem(const ElemParams& P, int mode, hipStream_t st);
+
+// deterministic two-stage reductions into a device scalar block
+void launch_reduce_partials(const double* partials, int64_t count, double* out, hipStream_t st);
+// stats[0] = sum v^2, stats[1] = number of non-finite entries (as double)
+void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st);
+void launch_dot(const double* a, const double* b, int64_t n, double* scratch, double* out, hipStream_t st);
+int64_t reduce_scratch_doubles(int64_t n);
+
+// y[i] = sum_j A[i,j] x[j]  (CSR, deterministic; wave-per-row when rows are long)
+void launch_csr_matvec(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val,
+                       const double* x, double* y, bool add, bool long_rows, hipStream_t st);
+// xn = x - s*n ; flag[0] |= any(xn != x)
+void launch_step(const double* x, const double* n, double s, double* xn, int64_t len, int32_t* moved,
+                 hipStream_t st);
+void launch_scale_copy(const double* src, double alpha, double* dst, int64_t len, hipStream_t st);
+void launch_axpy(double alpha, const double* x, double* y, int64_t len, hipStream_t st);
+
+// selection levels: H[q] = sum_{t in contributions(q)} slab[cidx[t]]
+void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,
+                            double* Hval, hipStream_t st);
+
+// general levels: H += panel' * Hel * panel per element, scattered by binary search + fp64 atomics
+struct PanelParams {
+    int32_t p, nu;
+    int64_t N;
+    const int32_t* ecol_ptr;      // [N*nu + 1] offsets into ecols / panel columns
+    const int32_t* ecols;         // column ids (global unknowns of this level)
+    const double* panels;         // per (element, state): p x c panel, column-major, at p * ecol_ptr[...]
+    const double* hel;
+    const int32_t* Hptr;
+    const int32_t* Hcol;
+    double* Hval;
+};
+void launch_panel_assemble(const PanelParams& P, hipStream_t st);
+
+}  // namespace mgbhip

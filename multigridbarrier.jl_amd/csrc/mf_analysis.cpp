@@ -1,0 +1,408 @@
+// mf_analysis.cpp -- ordering + symbolic factorization for the device multifrontal
+// Cholesky (see mf_analysis.hpp).  Host only.
+#include "mf_analysis.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include <unordered_map>
+
+namespace mgbhip {
+
+namespace {
+
+struct Graph {
+    int64_t n;
+    const int32_t* ptr;
+    const int32_t* idx;
+    bool adjacent(int32_t a, int32_t b) const {
+        const int32_t* lo = idx + ptr[a];
+        const int32_t* hi = idx + ptr[a + 1];
+        return std::binary_search(lo, hi, b);
+    }
+};
+
+struct Builder {
+    Graph g;
+    MfOptions opt;
+    std::vector<int32_t> pos;       // elimination position of a node
+    std::vector<int32_t> sn_of;     // supernode of a node
+    std::vector<char> removed;      // ordered already
+    std::vector<std::vector<int32_t>> sn_piv;
+    int32_t next_pos = 0;
+
+    // scratch for the dissection
+    std::vector<int32_t> tag;       // subset membership id
+    std::vector<int32_t> lvl;       // BFS level
+    int32_t next_tag = 1;
+
+    void new_supernode(const int32_t* nodes, size_t cnt) {
+        int32_t s = (int32_t)sn_piv.size();
+        sn_piv.emplace_back(nodes, nodes + cnt);
+        for (size_t i = 0; i < cnt; ++i) {
+            pos[nodes[i]] = next_pos++;
+            sn_of[nodes[i]] = s;
+            removed[nodes[i]] = 1;
+        }
+    }
+
+    // ---- 1. simplicial peeling -----------------------------------------------------
+    void peel(MfPlan& plan) {
+        const int64_t n = g.n;
+        std::vector<int32_t> nb;
+        std::vector<char> sel(n, 0);
+        for (int round = 0; round < opt.max_peel_rounds; ++round) {
+            int64_t remaining = 0;
+            for (int64_t v = 0; v < n; ++v) remaining += !removed[v];
+            if (remaining == 0) break;
+            std::vector<int32_t> chosen;
+            std::fill(sel.begin(), sel.end(), 0);
+            for (int32_t v = 0; v < n; ++v) {
+                if (removed[v]) continue;
+                nb.clear();
+                bool blocked = false;
+                for (int32_t e = g.ptr[v]; e < g.ptr[v + 1]; ++e) {
+                    int32_t u = g.idx[e];
+                    if (u == v || removed[u]) continue;
+                    if (sel[u]) { blocked = true; break; }
+                    nb.push_back(u);
+                    if ((int32_t)nb.size() > opt.peel_max_degree) { blocked = true; break; }
+                }
+                if (blocked) continue;
+                bool clique = true;
+                for (size_t a = 0; a < nb.size() && clique; ++a)
+                    for (size_t b = a + 1; b < nb.size(); ++b)
+                        if (!g.adjacent(nb[a], nb[b])) { clique = false; break; }
+                if (!clique) continue;
+                sel[v] = 1;
+                chosen.push_back(v);
+            }
+            if (chosen.empty() || (double)chosen.size() < 0.02 * (double)remaining) break;
+            // group chosen nodes with identical remaining neighbourhoods (they are mutually
+            // non-adjacent by construction): one front per group, at most 16 pivots each
+            std::vector<std::pair<uint64_t, int32_t>> keyed;
+            keyed.reserve(chosen.size());
+            auto nbhash = [&](int32_t v) {
+                uint64_t h = 1469598103934665603ull;
+                for (int32_t e = g.ptr[v]; e < g.ptr[v + 1]; ++e) {
+                    int32_t u = g.idx[e];
+                    if (u == v || removed[u]) continue;
+                    h ^= (uint64_t)(uint32_t)u + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+                }
+                return h;
+            };
+            for (int32_t v : chosen) keyed.emplace_back(nbhash(v), v);
+            std::sort(keyed.begin(), keyed.end());
+            auto same_nb = [&](int32_t a, int32_t b) {
+                int32_t ea = g.ptr[a], eb = g.ptr[b];
+                const int32_t enda = g.ptr[a + 1], endb = g.ptr[b + 1];
+                while (true) {
+                    while (ea < enda && (g.idx[ea] == a || removed[g.idx[ea]])) ++ea;
+                    while (eb < endb && (g.idx[eb] == b || removed[g.idx[eb]])) ++eb;
+                    if (ea == enda || eb == endb) return ea == enda && eb == endb;
+                    if (g.idx[ea] != g.idx[eb]) return false;
+                    ++ea; ++eb;
+                }
+            };
+            std::vector<int32_t> group;
+            size_t i = 0;
+            std::vector<std::vector<int32_t>> groups;
+            while (i < keyed.size()) {
+                group.clear();
+                group.push_back(keyed[i].second);
+                size_t j = i + 1;
+                while (j < keyed.size() && keyed[j].first == keyed[i].first && group.size() < 16 &&
+                       same_nb(keyed[i].second, keyed[j].second)) {
+                    group.push_back(keyed[j].second);
+                    ++j;
+                }
+                groups.push_back(group);
+                i = j;
+            }
+            // removal happens after grouping so that `removed` is stable during same_nb
+            for (auto& grp : groups) new_supernode(grp.data(), grp.size());
+            plan.peeled += (int64_t)chosen.size();
+            plan.peel_rounds = round + 1;
+        }
+    }
+
+    // ---- 2. nested dissection --------------------------------------------------------
+    // BFS inside the subset tagged `id`; returns nodes in visit order, fills lvl.
+    void bfs(int32_t start, int32_t id, std::vector<int32_t>& order) {
+        order.clear();
+        order.push_back(start);
+        lvl[start] = 0;
+        tag[start] = -id;   // visited marker: negative of the id
+        for (size_t h = 0; h < order.size(); ++h) {
+            int32_t v = order[h];
+            for (int32_t e = g.ptr[v]; e < g.ptr[v + 1]; ++e) {
+                int32_t u = g.idx[e];
+                if (tag[u] != id) continue;   // outside subset or already visited
+                tag[u] = -id;
+                lvl[u] = lvl[v] + 1;
+                order.push_back(u);
+            }
+        }
+    }
+
+    void dissect(std::vector<int32_t>& nodes) {
+        if ((int32_t)nodes.size() <= opt.leaf_size) {
+            if (!nodes.empty()) new_supernode(nodes.data(), nodes.size());
+            return;
+        }
+        int32_t id = next_tag++;
+        for (int32_t v : nodes) tag[v] = id;
+        std::vector<int32_t> order;
+        bfs(nodes[0], id, order);
+        if (order.size() < nodes.size()) {
+            // disconnected: split off the reached component, no separator needed
+            std::vector<int32_t> rest;
+            rest.reserve(nodes.size() - order.size());
+            for (int32_t v : nodes)
+                if (tag[v] == id) rest.push_back(v);
+            std::vector<int32_t> comp(order);
+            nodes.clear();
+            nodes.shrink_to_fit();
+            dissect(comp);
+            dissect(rest);
+            return;
+        }
+        // second sweep from the far end for a longer level structure
+        int32_t far = order.back();
+        for (int32_t v : nodes) tag[v] = id;
+        bfs(far, id, order);
+        int32_t depth = lvl[order.back()];
+        if (depth < 2) {
+            new_supernode(nodes.data(), nodes.size());
+            return;
+        }
+        std::vector<int64_t> cnt(depth + 1, 0);
+        for (int32_t v : order) cnt[lvl[v]]++;
+        // choose the level whose removal best balances the two sides
+        int64_t total = (int64_t)order.size(), below = cnt[0];
+        int32_t best = 1;
+        double best_score = 1e300;
+        for (int32_t l = 1; l <= depth - 1; ++l) {
+            int64_t above = total - below - cnt[l];
+            double imbalance = (double)std::llabs(below - above) / (double)total;
+            double score = imbalance + 0.5 * (double)cnt[l] / (double)total * 8.0;
+            if (score < best_score) { best_score = score; best = l; }
+            below += cnt[l];
+        }
+        std::vector<int32_t> A, B, S;
+        for (int32_t v : order) {
+            if (lvl[v] < best) A.push_back(v);
+            else if (lvl[v] > best) B.push_back(v);
+            else {
+                bool touches = false;
+                for (int32_t e = g.ptr[v]; e < g.ptr[v + 1] && !touches; ++e) {
+                    int32_t u = g.idx[e];
+                    if (tag[u] == -id && lvl[u] == best + 1) touches = true;
+                }
+                (touches ? S : A).push_back(v);
+            }
+        }
+        nodes.clear();
+        nodes.shrink_to_fit();
+        order.clear();
+        order.shrink_to_fit();
+        if (S.empty() || B.empty()) {   // cannot happen for a connected level structure, keep safe
+            std::vector<int32_t> all(A);
+            all.insert(all.end(), B.begin(), B.end());
+            all.insert(all.end(), S.begin(), S.end());
+            new_supernode(all.data(), all.size());
+            return;
+        }
+        // the children re-tag their own subsets; S keeps tag -id and is never revisited
+        dissect(A);
+        dissect(B);
+        new_supernode(S.data(), S.size());
+    }
+};
+
+}  // namespace
+
+void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const MfOptions& opt,
+                MfPlan& plan) {
+    plan = MfPlan();
+    plan.n = n;
+    if (n == 0) { plan.level_ptr.assign(1, 0); return; }
+    if (n > INT32_MAX) throw std::runtime_error("mf_analyze: n exceeds 32-bit indexing");
+    Builder b{Graph{n, rowptr, colidx}, opt};
+    b.pos.assign(n, -1);
+    b.sn_of.assign(n, -1);
+    b.removed.assign(n, 0);
+    b.tag.assign(n, 0);
+    b.lvl.assign(n, 0);
+
+    b.peel(plan);
+    {
+        std::vector<int32_t> rest;
+        for (int32_t v = 0; v < n; ++v)
+            if (!b.removed[v]) rest.push_back(v);
+        b.dissect(rest);
+    }
+    const int32_t nsn = (int32_t)b.sn_piv.size();
+    const std::vector<int32_t>& pos = b.pos;
+
+    // ---- 3. symbolic factorization on the supernode partition --------------------------
+    std::vector<std::vector<int32_t>> sn_struct(nsn);
+    std::vector<std::vector<int32_t>> sn_child(nsn);
+    std::vector<int32_t> parent(nsn, -1);
+    {
+        std::vector<int32_t> mark(n, -1);
+        for (int32_t s = 0; s < nsn; ++s) {
+            auto& piv = b.sn_piv[s];
+            int32_t maxpos = pos[piv.back()];
+            for (int32_t v : piv) mark[v] = s;
+            auto& st = sn_struct[s];
+            for (int32_t v : piv)
+                for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+                    int32_t u = colidx[e];
+                    if (mark[u] != s && pos[u] > maxpos) { mark[u] = s; st.push_back(u); }
+                }
+            for (int32_t c : sn_child[s])
+                for (int32_t u : sn_struct[c])
+                    if (mark[u] != s && pos[u] > maxpos) { mark[u] = s; st.push_back(u); }
+            std::sort(st.begin(), st.end(), [&](int32_t a, int32_t c2) { return pos[a] < pos[c2]; });
+            if (!st.empty()) {
+                parent[s] = b.sn_of[st[0]];
+                sn_child[parent[s]].push_back(s);
+            }
+        }
+    }
+
+    // ---- exact-fit amalgamation of a child into its parent ------------------------------
+    std::vector<int32_t> merged_into(nsn, -1);
+    {
+        std::vector<int32_t> extra_piv(nsn, 0);   // pivots already merged into a parent
+        for (int32_t s = 0; s < nsn; ++s) {
+            int32_t f = parent[s];
+            if (f < 0) continue;
+            size_t kf = b.sn_piv[f].size() - (size_t)extra_piv[f];   // original pivots of f
+            if (sn_struct[s].size() != kf + sn_struct[f].size()) continue;
+            int64_t ks = (int64_t)b.sn_piv[s].size();
+            if ((int64_t)extra_piv[f] * ks > 64) continue;          // zeros between merged siblings
+            if (ks + (int64_t)b.sn_piv[f].size() > 64 && extra_piv[f] > 0) continue;
+            // merge: child's pivots go first (they are eliminated earlier)
+            std::vector<int32_t> np(b.sn_piv[s]);
+            np.insert(np.end(), b.sn_piv[f].begin(), b.sn_piv[f].end());
+            // keep pos-order inside the pivot list
+            std::sort(np.begin(), np.end(), [&](int32_t a, int32_t c2) { return pos[a] < pos[c2]; });
+            b.sn_piv[f].swap(np);
+            extra_piv[f] += (int32_t)ks;
+            merged_into[s] = f;
+            // re-parent s's children to f
+            auto& cf = sn_child[f];
+            cf.erase(std::remove(cf.begin(), cf.end(), s), cf.end());
+            for (int32_t c : sn_child[s]) { parent[c] = f; cf.push_back(c); }
+            sn_child[s].clear();
+            b.sn_piv[s].clear();
+            sn_struct[s].clear();
+        }
+    }
+
+    // ---- levels, final numbering ----------------------------------------------------------
+    std::vector<int32_t> level(nsn, 0);
+    for (int32_t s = 0; s < nsn; ++s) {
+        if (merged_into[s] >= 0) continue;
+        int32_t l = 0;
+        for (int32_t c : sn_child[s]) l = std::max(l, level[c] + 1);
+        level[s] = l;
+    }
+    std::vector<int32_t> live;
+    for (int32_t s = 0; s < nsn; ++s)
+        if (merged_into[s] < 0) live.push_back(s);
+    auto msize = [&](int32_t s) { return (int32_t)(b.sn_piv[s].size() + sn_struct[s].size()); };
+    std::stable_sort(live.begin(), live.end(), [&](int32_t a, int32_t c2) {
+        if (level[a] != level[c2]) return level[a] < level[c2];
+        return msize(a) < msize(c2);
+    });
+    std::vector<int32_t> newid(nsn, -1);
+    for (size_t i = 0; i < live.size(); ++i) newid[live[i]] = (int32_t)i;
+
+    const int32_t nf = (int32_t)live.size();
+    plan.fronts.resize(nf);
+    int32_t maxlevel = 0;
+    for (int32_t i = 0; i < nf; ++i) {
+        int32_t s = live[i];
+        Front& f = plan.fronts[i];
+        f.k = (int32_t)b.sn_piv[s].size();
+        f.m = msize(s);
+        f.level = level[s];
+        f.parent = parent[s] >= 0 ? newid[parent[s]] : -1;
+        maxlevel = std::max(maxlevel, f.level);
+        f.idx_off = (int64_t)plan.front_idx.size();
+        plan.front_idx.insert(plan.front_idx.end(), b.sn_piv[s].begin(), b.sn_piv[s].end());
+        plan.front_idx.insert(plan.front_idx.end(), sn_struct[s].begin(), sn_struct[s].end());
+        f.F_off = plan.arena_doubles;
+        plan.arena_doubles += (int64_t)f.m * f.m;
+        f.u_off = plan.uvec_doubles;
+        plan.uvec_doubles += f.m - f.k;
+        plan.max_m = std::max(plan.max_m, f.m);
+        for (int32_t j = 0; j < f.k; ++j) {
+            int64_t r = f.m - j;
+            plan.factor_flops += r * r;
+        }
+        f.child_off = (int64_t)plan.children.size();
+        f.nchild = (int32_t)sn_child[s].size();
+        // children sorted by their new id => deterministic extend-add order
+        std::vector<int32_t> ch;
+        for (int32_t c : sn_child[s]) ch.push_back(newid[c]);
+        std::sort(ch.begin(), ch.end());
+        plan.children.insert(plan.children.end(), ch.begin(), ch.end());
+    }
+    plan.level_ptr.assign(maxlevel + 2, 0);
+    for (int32_t i = 0; i < nf; ++i) plan.level_ptr[plan.fronts[i].level + 1]++;
+    for (int32_t l = 0; l <= maxlevel; ++l) plan.level_ptr[l + 1] += plan.level_ptr[l];
+
+    // ---- relative indices + A scatter lists ------------------------------------------------
+    std::vector<int32_t> loc(n, -1);
+    // rel: positions of a front's boundary inside its parent's index list
+    for (int32_t i = 0; i < nf; ++i) {
+        Front& f = plan.fronts[i];
+        f.rel_off = (int64_t)plan.rel.size();
+        plan.rel.resize(plan.rel.size() + (size_t)(f.m - f.k), -1);
+    }
+    for (int32_t i = 0; i < nf; ++i) {
+        Front& f = plan.fronts[i];
+        const int32_t* idx = plan.front_idx.data() + f.idx_off;
+        for (int32_t j = 0; j < f.m; ++j) loc[idx[j]] = j;
+        // children of i
+        for (int32_t c = 0; c < f.nchild; ++c) {
+            Front& ch = plan.fronts[plan.children[f.child_off + c]];
+            const int32_t* cidx = plan.front_idx.data() + ch.idx_off + ch.k;
+            for (int32_t j = 0; j < ch.m - ch.k; ++j) {
+                int32_t p = loc[cidx[j]];
+                if (p < 0) throw std::runtime_error("mf_analyze: child boundary not contained in parent front");
+                plan.rel[ch.rel_off + j] = p;
+            }
+        }
+        // A entries owned by this front: pairs {v,u}, v a pivot, u == v or eliminated later
+        f.a_off = (int64_t)plan.a_src.size();
+        for (int32_t lv = 0; lv < f.k; ++lv) {
+            int32_t v = idx[lv];
+            for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+                int32_t u = colidx[e];
+                if (u != v && pos[u] < pos[v]) continue;
+                int32_t lu = loc[u];
+                if (lu < 0 || lu < lv) throw std::runtime_error("mf_analyze: structure violation in A scatter");
+                int32_t src = e;
+                if (u < v) {   // symmetric(H) reads the upper triangle: entry (u, v) in row u
+                    const int32_t* lo = colidx + rowptr[u];
+                    const int32_t* hi = colidx + rowptr[u + 1];
+                    const int32_t* it = std::lower_bound(lo, hi, v);
+                    if (it == hi || *it != v) throw std::runtime_error("mf_analyze: pattern is not symmetric");
+                    src = (int32_t)(it - colidx);
+                }
+                plan.a_src.push_back(src);
+                plan.a_dst.push_back(lu + lv * f.m);
+            }
+        }
+        f.a_cnt = (int32_t)((int64_t)plan.a_src.size() - f.a_off);
+        for (int32_t j = 0; j < f.m; ++j) loc[idx[j]] = -1;
+    }
+}
+
+}  // namespace mgbhip

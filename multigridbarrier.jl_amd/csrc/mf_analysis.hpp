@@ -1,0 +1,68 @@
+// mf_analysis.hpp -- symbolic analysis for the multifrontal sparse Cholesky that
+// replaces the reference's `solve(symmetric(H), g)` (reference: src/newton.jl:253,
+// src/utils.jl:142-145 -> Julia stdlib CHOLMOD; ext/MultiGridBarrierCUDAExt/cudss_solver.jl
+// on CUDA).  Pure host C++ (no HIP), so the ordering / tree / index maps can be unit
+// tested on the CPU; the numeric phase runs on the device (mf_numeric.hip).
+//
+// Pipeline
+//   1. simplicial peeling: repeatedly order nodes whose remaining neighbourhood is a
+//      clique (zero fill).  On the fine level this removes the broken slack DoFs
+//      (H_ss is diagonal because D_s = id) and then the element bubbles, i.e. the
+//      classical FEM static condensation, discovered from the graph alone;
+//   2. nested dissection of the rest by BFS level-set bisection with separator
+//      trimming; leaves of <= leaf_size nodes;
+//   3. supernodal symbolic factorization on that partition (exact row structures),
+//      exact-fit amalgamation of a child into its parent, relative index maps,
+//      level schedule (leaves first).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace mgbhip {
+
+struct Front {
+    int32_t k = 0;            // pivots
+    int32_t m = 0;            // pivots + boundary
+    int64_t idx_off = 0;      // into MfPlan::front_idx (m entries: global node ids)
+    int64_t F_off = 0;        // into the frontal-matrix arena (m*m doubles, column-major, ld = m)
+    int64_t u_off = 0;        // into the update-vector arena (m - k doubles)
+    int32_t parent = -1;
+    int32_t level = 0;
+    int64_t child_off = 0;    // into MfPlan::children
+    int32_t nchild = 0;
+    int64_t rel_off = 0;      // into MfPlan::rel: (m-k) positions of this front's boundary in its parent
+    int64_t a_off = 0;        // into MfPlan::a_src / a_dst
+    int32_t a_cnt = 0;
+};
+
+struct MfPlan {
+    int64_t n = 0;
+    std::vector<Front> fronts;          // sorted by (level, size class)
+    std::vector<int32_t> front_idx;     // concatenated index lists (global node ids)
+    std::vector<int32_t> children;      // concatenated child front ids
+    std::vector<int32_t> rel;           // concatenated relative indices
+    std::vector<int32_t> a_src;         // CSR value index of H feeding a_dst
+    std::vector<int32_t> a_dst;         // position row + col*m inside the front
+    std::vector<int32_t> level_ptr;     // fronts [level_ptr[l], level_ptr[l+1]) are level l
+    int64_t arena_doubles = 0;          // sum m*m
+    int64_t uvec_doubles = 0;           // sum (m-k)
+    int32_t max_m = 0;
+    int64_t factor_flops = 0;
+    // statistics
+    int64_t peeled = 0;
+    int32_t peel_rounds = 0;
+};
+
+struct MfOptions {
+    int32_t leaf_size = 32;
+    int32_t max_peel_rounds = 4;
+    int32_t peel_max_degree = 48;
+};
+
+// Symmetric pattern in CSR (both triangles present, diagonal optional).  Values are not
+// needed: the plan records, for every structural pair {v,u}, the CSR position of the
+// entry in the upper triangle (row <= col), which is what `symmetric(H)` reads.
+void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const MfOptions& opt,
+                MfPlan& plan);
+
+}  // namespace mgbhip

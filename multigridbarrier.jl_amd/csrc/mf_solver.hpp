@@ -1,0 +1,45 @@
+// mf_solver.hpp -- device multifrontal sparse Cholesky: `n = solve(symmetric(H), g)`
+// (reference: src/newton.jl:253, src/utils.jl:142-145; CUDA twin: cuDSS ANALYSIS once
+// per pattern, FACTORIZATION + SOLVE per Newton iteration,
+// ext/MultiGridBarrierCUDAExt/cudss_solver.jl:264-381).  Same life cycle here:
+// analyze() once per sparsity pattern (host, cached by the level), factor() + solve()
+// per Newton iteration on the device, all on the caller's stream.
+#pragma once
+#include "common.hpp"
+#include "mf_analysis.hpp"
+
+namespace mgbhip {
+
+struct FrontDev {
+    int32_t k, m, nchild, a_cnt;
+    int64_t F_off, idx_off, u_off, child_off, rel_off, a_off;
+};
+
+struct MfLaunch {          // one kernel launch: a contiguous range of fronts of one size class
+    int32_t first, count;
+    int32_t cls;           // LDS working size (0 = global-memory path)
+};
+
+class MfSolver {
+   public:
+    MfPlan plan;
+    void analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st);
+    // factor the matrix whose CSR values (same pattern as analyze) live at d_values.
+    // Asynchronous; the not-SPD flag is read back by status().
+    void factor(const double* d_values, hipStream_t st, StageTimers* timers);
+    // x = A^{-1} b (device vectors of length n; x may alias b)
+    void solve(const double* d_b, double* d_x, hipStream_t st, StageTimers* timers);
+    int status(hipStream_t st);     // synchronises; MGBHIP_OK or MGBHIP_ERR_NOT_SPD
+    bool analyzed = false;
+
+   private:
+    DevBuf<FrontDev> d_fronts;
+    DevBuf<int32_t> d_front_idx, d_children, d_rel, d_a_src, d_a_dst;
+    DevBuf<double> d_arena, d_uvec, d_y, d_tbig;
+    bool d_tbig_ready = false;
+    DevBuf<int32_t> d_status;
+    std::vector<std::vector<MfLaunch>> level_launches;   // per level, leaves first
+    int32_t lds_cap = 88;           // largest m factored out of LDS
+};
+
+}  // namespace mgbhip

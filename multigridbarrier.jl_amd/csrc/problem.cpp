@@ -1,0 +1,430 @@
+// problem.cpp -- native_to_device for one (AMG, Convex) pair, the per-level R'HR assembly
+// plans, and the device-resident f0/f1/f2/solve primitives behind the C ABI.
+#include "problem.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+using namespace mgbhip;
+
+// ---------------------------------------------------------------------------------------------
+// problem construction
+// ---------------------------------------------------------------------------------------------
+
+static void upload_csr(const mgbhip_csr& R, Level& L, hipStream_t st) {
+    MGB_REQUIRE(R.rows >= 0 && R.cols >= 0 && R.rowptr && (R.rowptr[R.rows] == 0 || (R.colidx && R.values)),
+                "bad prolongation CSR");
+    MGB_REQUIRE(R.rows < INT32_MAX && R.cols < INT32_MAX, "prolongation too large for 32-bit indices");
+    L.rows = R.rows;
+    L.m = R.cols;
+    const int64_t nnz = R.rowptr[R.rows];
+    L.hRptr.assign(R.rowptr, R.rowptr + R.rows + 1);
+    L.hRcol.assign(R.colidx, R.colidx + nnz);
+    L.hRval.assign(R.values, R.values + nnz);
+    for (int64_t i = 0; i < R.rows; ++i) {
+        MGB_REQUIRE(L.hRptr[i] <= L.hRptr[i + 1], "CSR row pointers must be non-decreasing");
+        for (int32_t q = L.hRptr[i]; q < L.hRptr[i + 1]; ++q)
+            MGB_REQUIRE(L.hRcol[q] >= 0 && L.hRcol[q] < R.cols, "CSR column index out of range");
+    }
+    L.Rptr.upload(L.hRptr, st);
+    L.Rcol.upload(L.hRcol.data(), L.hRcol.size(), st);
+    L.Rval.upload(L.hRval.data(), L.hRval.size(), st);
+    if (L.hRcol.empty()) { L.Rcol.alloc(1); L.Rval.alloc(1); }
+    // transpose (CSR of R') for the gather form of R' * v
+    std::vector<int32_t> tp(R.cols + 1, 0), tc(nnz);
+    std::vector<double> tv(nnz);
+    for (int64_t q = 0; q < nnz; ++q) tp[L.hRcol[q] + 1]++;
+    for (int64_t j = 0; j < R.cols; ++j) tp[j + 1] += tp[j];
+    std::vector<int32_t> fill(tp.begin(), tp.end() - 1);
+    int32_t maxrow = 0;
+    for (int64_t i = 0; i < R.rows; ++i)
+        for (int32_t q = L.hRptr[i]; q < L.hRptr[i + 1]; ++q) {
+            int32_t d = fill[L.hRcol[q]]++;
+            tc[d] = (int32_t)i;
+            tv[d] = L.hRval[q];
+        }
+    for (int64_t j = 0; j < R.cols; ++j) maxrow = std::max(maxrow, tp[j + 1] - tp[j]);
+    L.T_long = maxrow > 64;
+    L.Tptr.upload(tp, st);
+    L.Tcol.upload(tc.data(), tc.size(), st);
+    L.Tval.upload(tv.data(), tv.size(), st);
+    if (tc.empty()) { L.Tcol.alloc(1); L.Tval.alloc(1); }
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+static const double* upload_grid(mgbhip_problem* P, const double* h, size_t count) {
+    if (!h) return nullptr;
+    P->cone_grids.emplace_back();
+    P->cone_grids.back().upload(h, count, P->stream());
+    return P->cone_grids.back().p;
+}
+
+mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mgbhip_problem* share) {
+    MGB_REQUIRE(ctx && d, "null argument");
+    MGB_REQUIRE(d->p >= 1 && d->p <= 64, "nodes per element must be in 1..64");
+    MGB_REQUIRE(d->N >= 1, "need at least one element");
+    MGB_REQUIRE(d->nu >= 1 && d->nu <= MGBHIP_MAX_NU, "state components out of range");
+    MGB_REQUIRE(d->nD >= 1 && d->nD <= MGBHIP_MAX_ND, "D rows out of range");
+    MGB_REQUIRE(d->n_ops >= 1 && d->n_ops <= MGBHIP_MAX_OPS, "operator count out of range");
+    MGB_REQUIRE(d->L >= 1 && d->R && d->w, "missing hierarchy or weights");
+    MGB_HIP_CHECK(hipSetDevice(ctx->device));
+    std::unique_ptr<mgbhip_problem> P(new mgbhip_problem());
+    P->ctx = ctx;
+    P->p = d->p;
+    P->N = d->N;
+    P->n = (int64_t)d->p * d->N;
+    P->nu = d->nu;
+    P->nD = d->nD;
+    MGB_REQUIRE((int64_t)P->nu * P->n < INT32_MAX, "problem too large for 32-bit row indices");
+    hipStream_t st = ctx->stream;
+    const size_t blk = (size_t)d->p * d->p * d->N;
+    if (share) {
+        MGB_REQUIRE(share->ctx == ctx && share->p == P->p && share->N == P->N, "share: incompatible problem");
+        MGB_REQUIRE((int)share->store->ops.size() >= d->n_ops, "share: operator list mismatch");
+        P->store = share->store;
+    } else {
+        P->store = std::make_shared<OpStore>();
+        P->store->ops.resize(d->n_ops);
+        P->store->identity.resize(d->n_ops);
+        for (int o = 0; o < d->n_ops; ++o) {
+            P->store->identity[o] = d->ops[o] == nullptr;
+            if (d->ops[o]) P->store->ops[o].upload(d->ops[o], blk, st);
+        }
+        P->store->w.upload(d->w, (size_t)P->n, st);
+    }
+    // D table + LDS staging decision
+    P->nstage = 0;
+    int slot_of_op[MGBHIP_MAX_OPS];
+    for (int o = 0; o < MGBHIP_MAX_OPS; ++o) slot_of_op[o] = -1;
+    const int G = elem_group(P->p);
+    const int EPB = 256 / G;
+    for (int k = 0; k < d->nD; ++k) {
+        MGB_REQUIRE(d->D_state[k] >= 0 && d->D_state[k] < d->nu, "D row references a missing state variable");
+        MGB_REQUIRE(d->D_op[k] >= 0 && d->D_op[k] < d->n_ops, "D row references a missing operator");
+        P->D_state[k] = d->D_state[k];
+        P->D_op[k] = d->D_op[k];
+        const int o = d->D_op[k];
+        if (P->store->identity[o]) { P->D_stage[k] = -1; continue; }
+        if (slot_of_op[o] < 0) {
+            // stage through LDS while the operator tiles of one workgroup stay under 64 KB
+            size_t bytes = (size_t)(P->nstage + 1) * EPB * P->p * P->p * sizeof(double);
+            if (bytes <= 64 * 1024) {
+                slot_of_op[o] = P->nstage;
+                P->stage_ptr[P->nstage++] = P->store->ops[o].p;
+            } else {
+                slot_of_op[o] = -2;
+            }
+        }
+        P->D_stage[k] = slot_of_op[o];
+    }
+    for (int k = d->nD; k < MGBHIP_MAX_ND; ++k) { P->D_state[k] = -1; P->D_op[k] = 0; P->D_stage[k] = -1; }
+
+    // cone
+    const mgbhip_cone& C = d->cone;
+    MGB_REQUIRE(C.npieces >= 1 && C.npieces <= MGBHIP_MAX_PIECES, "unsupported number of convex pieces");
+    std::memset(&P->cone, 0, sizeof(P->cone));
+    P->cone.npieces = C.npieces;
+    P->cone.feasibility = C.feasibility;
+    P->cone.NC = C.NC;
+    P->cone.box_b = 1.0;
+    P->cone.box_R = 1.0;
+    const int ny_piece = C.feasibility ? C.NC - 1 : d->nD;    // pieces index into the user D rows
+    if (C.feasibility) MGB_REQUIRE(C.NC >= 2 && C.NC <= d->nD, "phase-I wrapper: bad NC");
+    for (int k = 0; k < C.npieces; ++k) {
+        const mgbhip_piece& s = C.pieces[k];
+        PieceDev& t = P->cone.pc[k];
+        MGB_REQUIRE(s.kind == MGBHIP_KIND_EP || s.kind == MGBHIP_KIND_LINEAR, "unknown functor family");
+        MGB_REQUIRE(s.ni >= 1 && s.ni <= MGBHIP_MAX_IDX, "functor index list too long for this build");
+        t.kind = s.kind;
+        t.ni = s.ni;
+        t.nc = (s.kind == MGBHIP_KIND_EP) ? s.ni : s.nc;
+        MGB_REQUIRE(t.nc >= 1 && t.nc <= MGBHIP_MAX_IDX, "functor constraint count too large for this build");
+        if (s.kind == MGBHIP_KIND_EP) MGB_REQUIRE(s.ni >= 2, "Euclidean power cone needs nz >= 2");
+        for (int c = 0; c < MGBHIP_MAX_IDX; ++c) {
+            t.idx[c] = c < s.ni ? s.idx[c] : 0;
+            if (c < s.ni) MGB_REQUIRE(s.idx[c] >= 0 && s.idx[c] < ny_piece, "functor index outside the D rows");
+        }
+        if (!s.A) MGB_REQUIRE(t.nc == t.ni, "identity A needs a square constraint matrix");
+        t.A = upload_grid(P.get(), s.A, (size_t)P->n * t.nc * t.ni);
+        t.b = upload_grid(P.get(), s.b, (size_t)P->n * t.nc);
+        t.p = upload_grid(P.get(), s.p, (size_t)P->n);
+        t.mu = upload_grid(P.get(), s.mu, (size_t)P->n);
+        t.select = upload_grid(P.get(), s.select, (size_t)P->n);
+        t.p_const = s.p_const;
+        t.mu_const = s.mu_const;
+        if (s.kind == MGBHIP_KIND_EP && !s.p) MGB_REQUIRE(s.p_const >= 1.0, "power cone exponent must be >= 1");
+    }
+    if (d->barrier_weights) {
+        P->bw.upload(d->barrier_weights, (size_t)P->n, st);
+        P->has_bw = true;
+    }
+    // hierarchy
+    P->levels.resize(d->L);
+    for (int l = 0; l < d->L; ++l) {
+        MGB_REQUIRE(d->R[l].rows == (int64_t)P->nu * P->n, "prolongation row count must be nu*n");
+        upload_csr(d->R[l], P->levels[l], st);
+    }
+    // workspace
+    int64_t mmax = 1;
+    for (auto& L : P->levels) mmax = std::max(mmax, L.m);
+    const size_t zn = (size_t)P->nu * P->n;
+    P->d_z.alloc(zn);
+    P->d_z0.alloc(zn);
+    P->d_c.alloc((size_t)P->n * P->nD);
+    P->d_c0.alloc((size_t)P->n * P->nD);
+    P->d_ret.alloc(zn);
+    P->d_hel.alloc((size_t)P->N * hel_blocks(P->nu) * P->p * P->p);
+    P->d_partials.alloc((size_t)elem_grid(P->p, P->N));
+    P->d_scal.alloc(16);
+    P->d_scratch.alloc((size_t)reduce_scratch_doubles(std::max<int64_t>(mmax, (int64_t)zn)));
+    P->d_nodeF.alloc((size_t)P->n);
+    P->d_x.alloc(mmax); P->d_g.alloc(mmax); P->d_nv.alloc(mmax); P->d_xn.alloc(mmax);
+    P->d_gn.alloc(mmax); P->d_tmp.alloc(mmax);
+    P->d_flag.alloc(4);
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    return P.release();
+}
+
+// ---------------------------------------------------------------------------------------------
+// assembly plan (reference: _make_block_assembly_plan, src/BlockMatrices.jl:322-491; the
+// CUDA twin builds dense panels + Int32 scatter maps, block_ops.jl:251-411)
+// ---------------------------------------------------------------------------------------------
+
+void mgbhip_problem::ensure_plan(int level) {
+    Level& L = levels[level];
+    if (L.planned) return;
+    hipStream_t st = stream();
+    const int64_t NE = N;
+    const int pp = p;
+    const int64_t nn = n;
+    // 1. per (element, state) column sets
+    bool selection = true;
+    for (size_t q = 0; q < L.hRval.size() && selection; ++q) selection = (L.hRval[q] == 1.0);
+    for (int64_t i = 0; i < L.rows && selection; ++i) selection = (L.hRptr[i + 1] - L.hRptr[i] <= 1);
+    std::vector<int32_t> ecol_ptr((size_t)NE * nu + 1, 0);
+    std::vector<int32_t> ecols;
+    ecols.reserve((size_t)NE * nu * pp);
+    std::vector<int32_t> tmp;
+    for (int64_t e = 0; e < NE; ++e)
+        for (int a = 0; a < nu; ++a) {
+            tmp.clear();
+            for (int r = 0; r < pp; ++r) {
+                const int64_t row = (int64_t)a * nn + e * pp + r;
+                for (int32_t q = L.hRptr[row]; q < L.hRptr[row + 1]; ++q) tmp.push_back(L.hRcol[q]);
+            }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            ecols.insert(ecols.end(), tmp.begin(), tmp.end());
+            ecol_ptr[e * nu + a + 1] = (int32_t)ecols.size();
+            MGB_REQUIRE(ecols.size() < (size_t)INT32_MAX, "assembly plan exceeds 32-bit indexing");
+        }
+    // 2. output pattern: union over elements of (all columns of e) x (all columns of e)
+    const int64_t m = L.m;
+    std::vector<int32_t> cnt(m + 1, 0);
+    for (int64_t e = 0; e < NE; ++e)
+        for (int32_t q = ecol_ptr[e * nu]; q < ecol_ptr[(e + 1) * nu]; ++q) cnt[ecols[q] + 1]++;
+    for (int64_t j = 0; j < m; ++j) cnt[j + 1] += cnt[j];
+    std::vector<int32_t> c2e(cnt[m]);
+    {
+        std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
+        for (int64_t e = 0; e < NE; ++e)
+            for (int32_t q = ecol_ptr[e * nu]; q < ecol_ptr[(e + 1) * nu]; ++q) c2e[fill[ecols[q]]++] = (int32_t)e;
+    }
+    L.hHptr.assign(m + 1, 0);
+    L.hHcol.clear();
+    std::vector<int32_t> rowbuf;
+    for (int64_t i = 0; i < m; ++i) {
+        rowbuf.clear();
+        for (int32_t t = cnt[i]; t < cnt[i + 1]; ++t) {
+            const int64_t e = c2e[t];
+            rowbuf.insert(rowbuf.end(), ecols.begin() + ecol_ptr[e * nu], ecols.begin() + ecol_ptr[(e + 1) * nu]);
+        }
+        if (rowbuf.empty()) rowbuf.push_back((int32_t)i);   // unknown untouched by any element: keep a diagonal slot
+        std::sort(rowbuf.begin(), rowbuf.end());
+        rowbuf.erase(std::unique(rowbuf.begin(), rowbuf.end()), rowbuf.end());
+        L.hHcol.insert(L.hHcol.end(), rowbuf.begin(), rowbuf.end());
+        MGB_REQUIRE(L.hHcol.size() < (size_t)INT32_MAX, "Hessian pattern exceeds 32-bit indexing");
+        L.hHptr[i + 1] = (int32_t)L.hHcol.size();
+    }
+    L.nnz = (int64_t)L.hHcol.size();
+    L.Hptr.upload(L.hHptr, st);
+    L.Hcol.upload(L.hHcol, st);
+    L.Hval.alloc((size_t)L.nnz);
+    L.selection = selection;
+    const int NB = hel_blocks(nu);
+    if (selection) {
+        // 3a. contribution lists: structural nonzero -> element-block slab entries, element order
+        std::vector<int32_t> ccount(L.nnz + 1, 0);
+        auto find = [&](int32_t row, int32_t col) {
+            const int32_t* lo = L.hHcol.data() + L.hHptr[row];
+            const int32_t* hi = L.hHcol.data() + L.hHptr[row + 1];
+            return (int32_t)(std::lower_bound(lo, hi, col) - L.hHcol.data());
+        };
+        auto colof = [&](int a, int64_t e, int r) -> int32_t {
+            const int64_t row = (int64_t)a * nn + e * pp + r;
+            return L.hRptr[row + 1] > L.hRptr[row] ? L.hRcol[L.hRptr[row]] : -1;
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<int32_t> fill;
+            std::vector<int32_t> cidx;
+            if (pass == 1) {
+                for (int64_t q = 0; q < L.nnz; ++q) ccount[q + 1] += ccount[q];
+                MGB_REQUIRE((int64_t)ccount[L.nnz] >= 0, "contribution list overflow");
+                fill.assign(ccount.begin(), ccount.end() - 1);
+                cidx.resize((size_t)ccount[L.nnz]);
+            }
+            for (int64_t e = 0; e < NE; ++e)
+                for (int a = 0; a < nu; ++a)
+                    for (int i = 0; i < pp; ++i) {
+                        const int32_t ci = colof(a, e, i);
+                        if (ci < 0) continue;
+                        for (int b = 0; b < nu; ++b)
+                            for (int j = 0; j < pp; ++j) {
+                                const int32_t cj = colof(b, e, j);
+                                if (cj < 0) continue;
+                                const int32_t pos = find(ci, cj);
+                                if (pass == 0) { ccount[pos + 1]++; continue; }
+                                // slab index of Hel_ab[i, j] (upper block triangle stored)
+                                int64_t src;
+                                if (a <= b) src = ((e * NB + hel_block_index(a, b, nu)) * pp + j) * (int64_t)pp + i;
+                                else src = ((e * NB + hel_block_index(b, a, nu)) * pp + i) * (int64_t)pp + j;
+                                MGB_REQUIRE(src < INT32_MAX, "element slab exceeds 32-bit indexing");
+                                cidx[fill[pos]++] = (int32_t)src;
+                            }
+                    }
+            if (pass == 1) {
+                L.cptr.upload(ccount, st);
+                L.cidx.upload(cidx.data(), cidx.size(), st);
+                if (cidx.empty()) L.cidx.alloc(1);
+                MGB_HIP_CHECK(hipStreamSynchronize(st));
+            }
+        }
+    } else {
+        // 3b. dense R panels per (element, state): p x c, column-major
+        std::vector<double> panels((size_t)pp * ecols.size(), 0.0);
+        for (int64_t e = 0; e < NE; ++e)
+            for (int a = 0; a < nu; ++a) {
+                const int32_t o = ecol_ptr[e * nu + a], c = ecol_ptr[e * nu + a + 1] - o;
+                for (int r = 0; r < pp; ++r) {
+                    const int64_t row = (int64_t)a * nn + e * pp + r;
+                    for (int32_t q = L.hRptr[row]; q < L.hRptr[row + 1]; ++q) {
+                        const int32_t* lo = ecols.data() + o;
+                        const int32_t ia = (int32_t)(std::lower_bound(lo, lo + c, L.hRcol[q]) - lo);
+                        panels[(size_t)pp * o + r + (size_t)pp * ia] += L.hRval[q];
+                    }
+                }
+            }
+        L.ecol_ptr.upload(ecol_ptr, st);
+        L.ecols.upload(ecols.data(), ecols.size(), st);
+        L.panels.upload(panels.data(), panels.size(), st);
+        if (ecols.empty()) { L.ecols.alloc(1); L.panels.alloc(1); }
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    L.planned = true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-resident primitives
+// ---------------------------------------------------------------------------------------------
+
+ElemParams mgbhip_problem::base_params(int level, const double* d_s, const double* d_zz, const double* d_cc) const {
+    ElemParams E;
+    std::memset(&E, 0, sizeof(E));
+    E.p = p; E.nu = nu; E.nD = nD; E.nstage = nstage; E.N = N; E.n = n;
+    for (size_t o = 0; o < store->ops.size() && o < MGBHIP_MAX_OPS; ++o) E.ops[o] = store->ops[o].p;
+    for (int o = 0; o < nstage; ++o) E.stage_ptr[o] = stage_ptr[o];
+    for (int k = 0; k < MGBHIP_MAX_ND; ++k) { E.D_state[k] = D_state[k]; E.D_op[k] = D_op[k]; E.D_stage[k] = D_stage[k]; }
+    E.w = store->w.p;
+    E.c = d_cc;
+    E.z0 = d_zz;
+    E.s = d_s;
+    if (level >= 0) {
+        const Level& L = levels[level];
+        E.Rptr = L.Rptr.p; E.Rcol = L.Rcol.p; E.Rval = L.Rval.p;
+    }
+    E.bw = has_bw ? bw.p : nullptr;
+    E.invn = 1.0 / (double)n;
+    E.cone = cone;
+    E.out_partial = d_partials.p;
+    E.out_ret = d_ret.p;
+    E.out_hel = d_hel.p;
+    E.out_F = d_nodeF.p;
+    E.out_Dz = nullptr;
+    return E;
+}
+
+double mgbhip_problem::eval_f0(int level, const double* d_s, const double* d_zz, const double* d_cc) {
+    hipStream_t st = stream();
+    ElemParams E = base_params(level, d_s, d_zz, d_cc);
+    {
+        StageScope sc(ctx->timers, "f0");
+        launch_elem(E, MODE_F0, st);
+        launch_reduce_partials(d_partials.p, elem_grid(p, N), d_scal.p, st);
+    }
+    double v = 0;
+    d_scal.download(&v, 1, st);
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    cnt.f0++;
+    return v;
+}
+
+void mgbhip_problem::eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout) {
+    hipStream_t st = stream();
+    ElemParams E = base_params(level, d_s, d_zz, d_cc);
+    const Level& L = levels[level];
+    {
+        StageScope sc(ctx->timers, "f1");
+        launch_elem(E, MODE_F1, st);
+    }
+    {
+        StageScope sc(ctx->timers, "restrict");
+        launch_csr_matvec(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, false, L.T_long, st);
+    }
+    cnt.f1++;
+}
+
+void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc) {
+    ensure_plan(level);
+    hipStream_t st = stream();
+    ElemParams E = base_params(level, d_s, d_zz, d_cc);
+    Level& L = levels[level];
+    {
+        StageScope sc(ctx->timers, "f2");
+        launch_elem(E, MODE_F2, st);
+    }
+    {
+        StageScope sc(ctx->timers, "assemble");
+        if (L.selection) {
+            launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, d_hel.p, L.Hval.p, st);
+        } else {
+            L.Hval.zero(st);
+            PanelParams PP;
+            PP.p = p; PP.nu = nu; PP.N = N;
+            PP.ecol_ptr = L.ecol_ptr.p; PP.ecols = L.ecols.p; PP.panels = L.panels.p;
+            PP.hel = d_hel.p; PP.Hptr = L.Hptr.p; PP.Hcol = L.Hcol.p; PP.Hval = L.Hval.p;
+            launch_panel_assemble(PP, st);
+        }
+    }
+    L.have_H = true;
+    L.factored = false;
+    cnt.f2++;
+}
+
+void mgbhip_problem::factor(int level) {
+    Level& L = levels[level];
+    MGB_REQUIRE(L.have_H, "solve requested before any Hessian was assembled at this level");
+    hipStream_t st = stream();
+    if (!L.solver.analyzed) L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st);
+    L.solver.factor(L.Hval.p, st, &ctx->timers);
+    L.factored = true;
+    cnt.factor++;
+}
+
+void mgbhip_problem::trisolve(int level, const double* d_g, double* d_xout) {
+    Level& L = levels[level];
+    MGB_REQUIRE(L.factored, "triangular solve before factorization");
+    L.solver.solve(d_g, d_xout, stream(), &ctx->timers);
+}

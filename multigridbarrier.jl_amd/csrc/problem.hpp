@@ -1,0 +1,82 @@
+// problem.hpp -- device-resident image of one (AMG, Convex) pair and its per-level plans.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mgbhip.h"
+#include "common.hpp"
+#include "kernels.hpp"
+#include "mf_solver.hpp"
+
+struct mgbhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    mgbhip::StageTimers timers;
+};
+
+namespace mgbhip {
+
+// Operator arrays + weights, shared between the (main, feasibility) problems of one solve
+// (the reference shares them by identity-memoised conversion, conversion.jl:1-11).
+struct OpStore {
+    std::vector<DevBuf<double>> ops;
+    std::vector<bool> identity;
+    DevBuf<double> w;
+};
+
+struct Level {
+    int64_t rows = 0, m = 0;
+    std::vector<int32_t> hRptr, hRcol;     // host copy of R (plan construction)
+    std::vector<double> hRval;
+    DevBuf<int32_t> Rptr, Rcol, Tptr, Tcol;
+    DevBuf<double> Rval, Tval;
+    bool T_long = false;
+    // assembly plan for H = R' H_blk R (reference: BlockAssemblyPlan, src/BlockMatrices.jl:281-491)
+    bool planned = false;
+    bool selection = false;               // every row of R has at most one entry, equal to 1
+    std::vector<int32_t> hHptr, hHcol;
+    DevBuf<int32_t> Hptr, Hcol, cptr, cidx, ecol_ptr, ecols;
+    DevBuf<double> Hval, panels;
+    int64_t nnz = 0;
+    MfSolver solver;
+    bool have_H = false, factored = false;
+};
+
+struct Counters {
+    int64_t f0 = 0, f1 = 0, f2 = 0, factor = 0, newton = 0;
+    double solve_seconds = 0;
+};
+
+}  // namespace mgbhip
+
+struct mgbhip_problem {
+    mgbhip_ctx* ctx = nullptr;
+    int32_t p = 0, nu = 0, nD = 0;
+    int64_t N = 0, n = 0;
+    std::shared_ptr<mgbhip::OpStore> store;
+    int32_t D_state[MGBHIP_MAX_ND], D_op[MGBHIP_MAX_ND], D_stage[MGBHIP_MAX_ND];
+    int32_t nstage = 0;
+    const double* stage_ptr[MGBHIP_MAX_OPS];
+    mgbhip::ConeDev cone;
+    std::vector<mgbhip::DevBuf<double>> cone_grids;
+    mgbhip::DevBuf<double> bw;
+    bool has_bw = false;
+    std::vector<mgbhip::Level> levels;
+    // workspace
+    mgbhip::DevBuf<double> d_z, d_z0, d_c, d_ret, d_hel, d_partials, d_scal, d_scratch, d_nodeF, d_nodeDz;
+    mgbhip::DevBuf<double> d_x, d_g, d_nv, d_xn, d_gn, d_tmp, d_c0;
+    mgbhip::DevBuf<int32_t> d_flag;
+    mgbhip::Counters cnt;
+
+    mgbhip::ElemParams base_params(int level, const double* d_s, const double* d_zz, const double* d_cc) const;
+    hipStream_t stream() const { return ctx->stream; }
+    void ensure_plan(int level);
+    double eval_f0(int level, const double* d_s, const double* d_zz, const double* d_cc);
+    void eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
+    void eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc);
+    // returns MGBHIP_OK or MGBHIP_ERR_NOT_SPD; x = H^{-1} g on the device
+    void factor(int level);
+    void trisolve(int level, const double* d_g, double* d_xout);
+};

@@ -1,0 +1,234 @@
+"""`mgb_solve`: the reference's top-level entry on the HIP backend.
+
+Mirrors `mgb_solve` / `mgb_driver` (reference: src/mgb.jl:798-842, :332-584): move the
+assembled problem to the device, probe feasibility of the start, run phase I with box
+escalation when needed, hand over with `_matched_t`, run the main t-ramp, move the solution
+back.  All loops below `mgb_core` (level sweep, Newton, line search) run inside
+`libmgbhip.so`; this file only orchestrates the rarely-taken phase-I branch and packs the
+diagnostics the reference returns in `MGBSOL`.
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+from . import device as dev
+from .device import ERR_CONVERGENCE, OK, DeviceMGBProblem, HIPDevice, native_to_device
+from .problem import MGBProblem
+
+EPS = float(np.finfo(np.float64).eps)
+
+
+class MGBConvergenceFailure(Exception):
+    """reference: src/utils.jl:178-184; `code` in {'infeasible', 'feasibility_Rmax', 'stall',
+    'iteration_limit', 'failure'}."""
+
+    def __init__(self, message: str, code: str = "failure"):
+        super().__init__(message)
+        self.message = message
+        self.code = code
+
+
+@dataclass
+class MGBSOL:
+    """reference: src/mgb.jl:637-643."""
+
+    z: np.ndarray
+    SOL_feasibility: Optional[Dict[str, Any]]
+    SOL_main: Dict[str, Any]
+    log: str
+    geometry: Any
+
+
+def _barrier_weights(w: np.ndarray, barrier_nodes):
+    """reference: src/convex.jl:279-304."""
+    if barrier_nodes is None or (isinstance(barrier_nodes, str) and barrier_nodes == "colon"):
+        return None
+    sel = np.asarray(barrier_nodes)
+    if sel.dtype == bool:
+        if sel.size != w.size:
+            raise ValueError(f"barrier_nodes mask has length {sel.size} but the mesh has {w.size} nodes")
+        nz = sel.astype(np.float64)
+    else:
+        if sel.size == 0:
+            raise ValueError("barrier_nodes must select at least one node")
+        if sel.min() < 0 or sel.max() >= w.size:
+            raise ValueError(f"barrier_nodes indices must lie in 0:{w.size - 1}")
+        nz = np.zeros(w.size)
+        nz[sel] = 1.0
+    m = nz.sum()
+    if m <= 0:
+        raise ValueError("barrier_nodes selects no nodes")
+    if m == nz.size:
+        return None
+    return nz / m
+
+
+def _options(P, tol, t, kappa, maxit, max_newton, line_search, stopping_criterion, finalize, early_stop):
+    o = P.default_options()
+    if tol is not None:
+        o.tol = float(tol)
+    o.t = float(t)
+    if kappa is not None:
+        o.kappa = float(kappa)
+    if maxit is not None:
+        o.maxit = int(maxit)
+    if max_newton is not None:
+        o.max_newton = int(max_newton)
+    if line_search is not None:
+        kind = line_search[0] if isinstance(line_search, (tuple, list)) else line_search
+        args = list(line_search[1:]) if isinstance(line_search, (tuple, list)) else []
+        if kind == "backtracking":
+            o.line_search = 0
+            if len(args) > 0:
+                o.ls_beta = float(args[0])
+            if len(args) > 1:
+                o.ls_c1 = float(args[1])
+        elif kind == "illinois":
+            o.line_search = 1
+            if len(args) > 0:
+                o.ls_beta = float(args[0])
+        else:
+            raise ValueError("line_search must be ('backtracking', beta, c1) or ('illinois', beta)")
+    if stopping_criterion is not None:
+        kind = stopping_criterion[0]
+        if kind == "inexact":
+            o.stop_lambda_tol, o.stop_theta = float(stopping_criterion[1]), float(stopping_criterion[2])
+        elif kind == "exact":
+            o.stop_lambda_tol, o.stop_theta = -1.0, float(stopping_criterion[1])
+        else:
+            raise ValueError("stopping_criterion must be ('inexact', lambda_tol, theta) or ('exact', theta)")
+    if finalize is False:
+        o.finalize = 0
+    elif finalize is not None and finalize is not True:
+        o.finalize, o.finalize_theta = 1, float(finalize[1] if isinstance(finalize, (tuple, list)) else finalize)
+    o.early_stop = int(early_stop)
+    return o
+
+
+def _run_core(P, z, c, opt, what):
+    status, znew, diag = P.mgb_core(z, c, opt, cap_steps=max(64, min(int(opt.maxit), 4096)))
+    diag["z"] = znew
+    if status == ERR_CONVERGENCE:
+        code = "iteration_limit" if diag["failure_code"] == 2 else "stall"
+        if diag["k"] == 1 and diag["failure_code"] == 1 and diag["t_final"] == opt.t:
+            msg = f"Initial centering failed in mgb_solve at t={opt.t}, tol={opt.tol}, maxit={opt.maxit}."
+        else:
+            msg = (f"Convergence failure in mgb_solve ({what}) at t={diag['t_final']}, k={diag['k']}, "
+                   f"tol={opt.tol}, maxit={opt.maxit}.")
+        raise MGBConvergenceFailure(msg, code)
+    return diag
+
+
+def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[float] = None,
+               feasibility_Rmax: float = 1.0 / math.sqrt(EPS), tol=None, kappa=None, maxit=None, max_newton=None,
+               stopping_criterion=None, line_search=None, finalize=None, barrier_nodes="default",
+               printlog=lambda *a: None, early_stop=None):
+    """reference: src/mgb.jl:332-584."""
+    if early_stop is not None:
+        raise NotImplementedError("user early_stop callbacks are not supported by the device-resident t-ramp")
+    prob = D.prob
+    main = D.main
+    M1 = prob.M[0]
+    if t_feasibility is None:
+        t_feasibility = t
+    if isinstance(barrier_nodes, str) and barrier_nodes == "default":
+        barrier_nodes = M1.w != 0
+    bw_main = _barrier_weights(M1.w, barrier_nodes)
+    m = M1.w.size
+    nD = len(M1.D_fine)
+    c0, z0 = prob.f, prob.g
+    ncomp = z0.shape[1]
+    z2 = np.ascontiguousarray(z0.T).reshape(-1).copy()
+    common = dict(tol=tol, kappa=kappa, maxit=maxit, max_newton=max_newton, line_search=line_search,
+                  stopping_criterion=stopping_criterion, finalize=finalize)
+    SOL_feasibility = None
+    F, w_Dz = main.node_barrier(z2, want_Dz=True)
+    if not np.all(np.isfinite(F)):
+        feas = D.feasibility
+        sl = main.node_slack(z2)
+        z1cols = np.concatenate([z0, (2 * np.maximum(sl, 1.0))[:, None]], axis=1)
+        b = 2 * max(1.0, float(z1cols[:, -1].max()))
+        c1 = np.zeros((m, nD + 1 + ncomp))
+        c1[:, nD] = 1.0
+        z1 = np.ascontiguousarray(z1cols.T).reshape(-1).copy()
+        slack_of = lambda z: z[ncomp * m:(ncomp + 1) * m]
+        feasible = lambda z: bool(slack_of(z).max() < 0)
+        Rbox = max(10.0, 10.0 * float(np.abs(z2).max()))
+        Rmax = max(float(feasibility_Rmax), Rbox)
+        while True:
+            printlog("mgb_driver: feasibility phase with bounding box R=", Rbox)
+            feas.set_box(float(b), Rbox)
+            failure = None
+            try:
+                opt = _options(feas, t=t_feasibility, early_stop=1, **common)
+                SOL_feasibility = _run_core(feas, z1, c1, opt, "feasibility phase")
+            except (MGBConvergenceFailure, dev.MGBHipError) as e2:   # each round is a probe (src/mgb.jl:505-515)
+                failure = e2
+            if failure is None:
+                zf = SOL_feasibility["z"]
+                if feasible(zf):
+                    break
+                vmax = max(float(np.abs(zf[k * m:(k + 1) * m]).max()) for k in range(ncomp))
+                smax = float(slack_of(zf).max())
+                if vmax <= Rbox / 2:
+                    raise MGBConvergenceFailure(
+                        "The problem appears to be infeasible: the feasibility subproblem converged to a minimizer "
+                        f"with positive constraint violation (max slack ~ {smax}) strictly inside the bounding box "
+                        f"(max |nodal value| ~ {vmax} <= R/2 with R = {Rbox}).", "infeasible")
+                printlog("mgb_driver: phase-I minimizer presses the box (max |nodal value|=", vmax,
+                         ", max slack=", smax, "); growing R")
+            else:
+                printlog("mgb_driver: feasibility solve failed at R=", Rbox, ": ", failure)
+            Rnext = 10 * Rbox
+            if Rnext > Rmax:
+                reason = ("the phase-I minimizer still presses against the bounding box" if failure is None
+                          else f"the last attempt failed with: {failure}")
+                raise MGBConvergenceFailure(
+                    f"Could not find a strictly feasible point with nodal values bounded by R = {Rbox} "
+                    f"(cap feasibility_Rmax ~ {Rmax}); {reason}. The problem is infeasible, or its feasible points "
+                    "have nodal values exceeding the cap (rescale the problem, or raise feasibility_Rmax).",
+                    "feasibility_Rmax")
+            Rbox = Rnext
+        z2 = SOL_feasibility["z"][: z2.size].copy()
+        main.set_barrier_weights(bw_main)
+        tm = main.matched_t(z2, c0, t)
+        printlog("_matched_t: starting main ramp at t=", tm)
+        t = min(t, tm)
+    main.set_barrier_weights(bw_main)
+    opt = _options(main, t=t, early_stop=0, **common)
+    SOL_main = _run_core(main, z2, c0, opt, "main phase")
+    z = SOL_main["z"].reshape(ncomp, m).T.copy()
+    return dict(z=z, SOL_feasibility=SOL_feasibility, SOL_main=SOL_main)
+
+
+def mgb_solve(prob: MGBProblem, device=None, verbose: bool = False, logfile=None, device_id: int = 0,
+              stream: Optional[int] = None, keep_device: bool = False, **rest) -> MGBSOL:
+    """reference: `mgb_solve`, src/mgb.jl:798-842."""
+    if device is None:
+        device = dev.default_device()
+    lines = []
+
+    def printlog(*args):
+        s = "".join(str(a) for a in args)
+        lines.append(s)
+        if logfile is not None:
+            print(s, file=logfile)
+
+    printlog("mgb_solve: device = ", getattr(device, "__name__", device))
+    D = native_to_device(device, prob, device_id=device_id, stream=stream)
+    try:
+        SOL = mgb_driver(D, printlog=printlog, **rest)
+    except BaseException:
+        D.close()          # the throw path flushes plans / factorizations too (src/mgb.jl:832-839)
+        raise
+    sol = MGBSOL(SOL["z"], SOL["SOL_feasibility"], SOL["SOL_main"], "\n".join(lines), prob.geometry)
+    if keep_device:
+        sol.device = D
+    else:
+        D.close()
+    return sol
