@@ -183,6 +183,10 @@ void mgbhip_default_options(mgbhip_options* opt, int64_t n_nodes);
  * from hipEvents on the handle's stream.                                               */
 int mgbhip_stage_ms(mgbhip_problem* prob, const char* stage, double* total_ms, int64_t* launches);
 int mgbhip_reset_stage_timers(mgbhip_problem* prob, int enable);
+/* Factorization statistics of a level (after its first solve): out[0] fronts, [1] largest
+ * front, [2] arena doubles, [3] factor flops, [4] peeled unknowns, [5] tree levels,
+ * [6] nnz(H), [7] unknowns.                                                             */
+int mgbhip_solver_stats(mgbhip_problem* prob, int32_t level, double* out8);
 
 #ifdef __cplusplus
 }

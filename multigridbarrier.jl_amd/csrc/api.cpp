@@ -266,6 +266,24 @@ int mgbhip_stage_ms(mgbhip_problem* P, const char* stage, double* total_ms, int6
     MGB_API_END
 }
 
+int mgbhip_solver_stats(mgbhip_problem* P, int32_t level, double* out) {
+    MGB_API_BEGIN
+    check_level(P, level);
+    MGB_REQUIRE(out != nullptr, "null argument");
+    const Level& L = P->levels[level];
+    const MfPlan& pl = L.solver.plan;
+    out[0] = (double)pl.fronts.size();
+    out[1] = (double)pl.max_m;
+    out[2] = (double)pl.arena_doubles;
+    out[3] = (double)pl.factor_flops;
+    out[4] = (double)pl.peeled;
+    out[5] = pl.level_ptr.empty() ? 0.0 : (double)(pl.level_ptr.size() - 1);
+    out[6] = (double)L.nnz;
+    out[7] = (double)L.m;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
 int mgbhip_reset_stage_timers(mgbhip_problem* P, int enable) {
     MGB_API_BEGIN
     MGB_REQUIRE(P, "null argument");

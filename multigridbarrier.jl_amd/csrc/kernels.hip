@@ -361,12 +361,16 @@ __global__ __launch_bounds__(256) void gather_assemble_kernel(int64_t nnz, const
 }
 
 // General (coarse) levels: one workgroup per element; thread (ia, ib) computes
-// panel_a[:, ia]' * Hel_ab * panel_b[:, ib] and adds it into H (binary search in the CSR row).
-__global__ __launch_bounds__(256) void panel_assemble_kernel(const PanelParams P) {
+// panel_a[:, ia]' * Hel_ab * panel_b[:, ib] into the element's projected slab (deterministic;
+// the structural nonzeros of H gather from the slab afterwards).
+__global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P) {
     const int64_t e = blockIdx.x;
     const int p = P.p, nu = P.nu;
     const int NB = nu * (nu + 1) / 2;
     const int tid = threadIdx.x;
+    const int32_t base = P.ecol_ptr[e * nu];
+    const int32_t ct = P.ecol_ptr[(e + 1) * nu] - base;
+    double* out = P.slab + P.eoff[e];
     for (int a = 0; a < nu; ++a) {
         const int32_t oa = P.ecol_ptr[e * nu + a], ca = P.ecol_ptr[e * nu + a + 1] - oa;
         const double* pa = P.panels + (int64_t)p * oa;
@@ -389,14 +393,7 @@ __global__ __launch_bounds__(256) void panel_assemble_kernel(const PanelParams P
                     }
                     acc += inner * pbv;
                 }
-                const int32_t row = P.ecols[oa + ia], colv = P.ecols[ob + ib];
-                int32_t lo = P.Hptr[row], hi = P.Hptr[row + 1] - 1;
-                while (lo < hi) {
-                    const int32_t mid = (lo + hi) >> 1;
-                    if (P.Hcol[mid] < colv) lo = mid + 1;
-                    else hi = mid;
-                }
-                unsafeAtomicAdd(&P.Hval[lo], acc);
+                out[(oa - base + ia) + (int64_t)ct * (ob - base + ib)] = acc;
             }
         }
     }
@@ -545,9 +542,9 @@ void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cid
     MGB_HIP_CHECK(hipGetLastError());
 }
 
-void launch_panel_assemble(const PanelParams& P, hipStream_t st) {
+void launch_panel_project(const PanelParams& P, hipStream_t st) {
     if (P.N == 0) return;
-    hipLaunchKernelGGL(panel_assemble_kernel, dim3((unsigned)P.N), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(panel_project_kernel, dim3((unsigned)P.N), dim3(256), 0, st, P);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

@@ -62,18 +62,17 @@ void launch_axpy(double alpha, const double* x, double* y, int64_t len, hipStrea
 void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,
                             double* Hval, hipStream_t st);
 
-// general levels: H += panel' * Hel * panel per element, scattered by binary search + fp64 atomics
+// general (coarse) levels: slab_e = [panel_0 .. panel_{nu-1}]' * Hel_e * [panel_0 .. panel_{nu-1}]
+// (c_tot x c_tot, column-major, at eoff[e]); the structural nonzeros then gather from the slab.
 struct PanelParams {
     int32_t p, nu;
     int64_t N;
-    const int32_t* ecol_ptr;      // [N*nu + 1] offsets into ecols / panel columns
-    const int32_t* ecols;         // column ids (global unknowns of this level)
+    const int32_t* ecol_ptr;      // [N*nu + 1] offsets of the per-(element, state) column lists
     const double* panels;         // per (element, state): p x c panel, column-major, at p * ecol_ptr[...]
+    const int32_t* eoff;          // [N + 1] slab offsets
     const double* hel;
-    const int32_t* Hptr;
-    const int32_t* Hcol;
-    double* Hval;
+    double* slab;
 };
-void launch_panel_assemble(const PanelParams& P, hipStream_t st);
+void launch_panel_project(const PanelParams& P, hipStream_t st);
 
 }  // namespace mgbhip

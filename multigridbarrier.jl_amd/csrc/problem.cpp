@@ -254,27 +254,30 @@ void mgbhip_problem::ensure_plan(int level) {
     L.Hval.alloc((size_t)L.nnz);
     L.selection = selection;
     const int NB = hel_blocks(nu);
-    if (selection) {
-        // 3a. contribution lists: structural nonzero -> element-block slab entries, element order
-        std::vector<int32_t> ccount(L.nnz + 1, 0);
-        auto find = [&](int32_t row, int32_t col) {
-            const int32_t* lo = L.hHcol.data() + L.hHptr[row];
-            const int32_t* hi = L.hHcol.data() + L.hHptr[row + 1];
-            return (int32_t)(std::lower_bound(lo, hi, col) - L.hHcol.data());
-        };
-        auto colof = [&](int a, int64_t e, int r) -> int32_t {
-            const int64_t row = (int64_t)a * nn + e * pp + r;
-            return L.hRptr[row + 1] > L.hRptr[row] ? L.hRcol[L.hRptr[row]] : -1;
-        };
-        for (int pass = 0; pass < 2; ++pass) {
-            std::vector<int32_t> fill;
-            std::vector<int32_t> cidx;
-            if (pass == 1) {
-                for (int64_t q = 0; q < L.nnz; ++q) ccount[q + 1] += ccount[q];
-                MGB_REQUIRE((int64_t)ccount[L.nnz] >= 0, "contribution list overflow");
-                fill.assign(ccount.begin(), ccount.end() - 1);
-                cidx.resize((size_t)ccount[L.nnz]);
-            }
+    // 3. contribution lists: every structural nonzero of H gathers its summands from a slab in
+    //    element order (no atomics).  Selection levels read the element-block slab written by
+    //    the f2 kernel directly; general levels read the projected slab panel' * Hel * panel.
+    auto find = [&](int32_t row, int32_t col) {
+        const int32_t* lo = L.hHcol.data() + L.hHptr[row];
+        const int32_t* hi = L.hHcol.data() + L.hHptr[row + 1];
+        return (int32_t)(std::lower_bound(lo, hi, col) - L.hHcol.data());
+    };
+    std::vector<int64_t> eoff;
+    if (!selection) {
+        eoff.assign((size_t)NE + 1, 0);
+        for (int64_t e = 0; e < NE; ++e) {
+            const int64_t ct = ecol_ptr[(e + 1) * nu] - ecol_ptr[e * nu];
+            eoff[e + 1] = eoff[e] + ct * ct;
+        }
+        MGB_REQUIRE(eoff[NE] < (int64_t)INT32_MAX, "projected slab exceeds 32-bit indexing");
+        L.slab_doubles = eoff[NE];
+    }
+    auto colof = [&](int a, int64_t e, int r) -> int32_t {
+        const int64_t row = (int64_t)a * nn + e * pp + r;
+        return L.hRptr[row + 1] > L.hRptr[row] ? L.hRcol[L.hRptr[row]] : -1;
+    };
+    auto for_each = [&](auto&& emit) {
+        if (selection) {
             for (int64_t e = 0; e < NE; ++e)
                 for (int a = 0; a < nu; ++a)
                     for (int i = 0; i < pp; ++i) {
@@ -284,25 +287,44 @@ void mgbhip_problem::ensure_plan(int level) {
                             for (int j = 0; j < pp; ++j) {
                                 const int32_t cj = colof(b, e, j);
                                 if (cj < 0) continue;
-                                const int32_t pos = find(ci, cj);
-                                if (pass == 0) { ccount[pos + 1]++; continue; }
-                                // slab index of Hel_ab[i, j] (upper block triangle stored)
-                                int64_t src;
+                                int64_t src;   // slab index of Hel_ab[i, j] (upper block triangle stored)
                                 if (a <= b) src = ((e * NB + hel_block_index(a, b, nu)) * pp + j) * (int64_t)pp + i;
                                 else src = ((e * NB + hel_block_index(b, a, nu)) * pp + i) * (int64_t)pp + j;
-                                MGB_REQUIRE(src < INT32_MAX, "element slab exceeds 32-bit indexing");
-                                cidx[fill[pos]++] = (int32_t)src;
+                                emit(find(ci, cj), src);
                             }
                     }
-            if (pass == 1) {
-                L.cptr.upload(ccount, st);
-                L.cidx.upload(cidx.data(), cidx.size(), st);
-                if (cidx.empty()) L.cidx.alloc(1);
-                MGB_HIP_CHECK(hipStreamSynchronize(st));
+        } else {
+            for (int64_t e = 0; e < NE; ++e) {
+                const int32_t base = ecol_ptr[e * nu];
+                const int32_t ct = ecol_ptr[(e + 1) * nu] - base;
+                for (int32_t gj = 0; gj < ct; ++gj)
+                    for (int32_t gi = 0; gi < ct; ++gi)
+                        emit(find(ecols[base + gi], ecols[base + gj]), eoff[e] + gi + (int64_t)ct * gj);
             }
         }
-    } else {
-        // 3b. dense R panels per (element, state): p x c, column-major
+    };
+    {
+        std::vector<int32_t> ccount(L.nnz + 1, 0);
+        for_each([&](int32_t pos, int64_t) { ccount[pos + 1]++; });
+        int64_t total = 0;
+        for (int64_t q = 0; q < L.nnz; ++q) {
+            total += ccount[q + 1];
+            MGB_REQUIRE(total < (int64_t)INT32_MAX, "contribution list exceeds 32-bit indexing");
+            ccount[q + 1] += ccount[q];
+        }
+        std::vector<int32_t> fill(ccount.begin(), ccount.end() - 1);
+        std::vector<int32_t> cidx((size_t)total);
+        for_each([&](int32_t pos, int64_t src) {
+            MGB_REQUIRE(src < (int64_t)INT32_MAX, "slab exceeds 32-bit indexing");
+            cidx[fill[pos]++] = (int32_t)src;
+        });
+        L.cptr.upload(ccount, st);
+        L.cidx.upload(cidx.data(), cidx.size(), st);
+        if (cidx.empty()) L.cidx.alloc(1);
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (!selection) {
+        // dense R panels per (element, state): p x c, column-major
         std::vector<double> panels((size_t)pp * ecols.size(), 0.0);
         for (int64_t e = 0; e < NE; ++e)
             for (int a = 0; a < nu; ++a) {
@@ -316,10 +338,13 @@ void mgbhip_problem::ensure_plan(int level) {
                     }
                 }
             }
+        std::vector<int32_t> eoff32(eoff.begin(), eoff.end());
+        L.eoff.upload(eoff32, st);
         L.ecol_ptr.upload(ecol_ptr, st);
         L.ecols.upload(ecols.data(), ecols.size(), st);
         L.panels.upload(panels.data(), panels.size(), st);
         if (ecols.empty()) { L.ecols.alloc(1); L.panels.alloc(1); }
+        L.slab.alloc((size_t)std::max<int64_t>(L.slab_doubles, 1));
         MGB_HIP_CHECK(hipStreamSynchronize(st));
     }
     MGB_HIP_CHECK(hipStreamSynchronize(st));
@@ -400,12 +425,12 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
         if (L.selection) {
             launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, d_hel.p, L.Hval.p, st);
         } else {
-            L.Hval.zero(st);
             PanelParams PP;
             PP.p = p; PP.nu = nu; PP.N = N;
-            PP.ecol_ptr = L.ecol_ptr.p; PP.ecols = L.ecols.p; PP.panels = L.panels.p;
-            PP.hel = d_hel.p; PP.Hptr = L.Hptr.p; PP.Hcol = L.Hcol.p; PP.Hval = L.Hval.p;
-            launch_panel_assemble(PP, st);
+            PP.ecol_ptr = L.ecol_ptr.p; PP.panels = L.panels.p; PP.eoff = L.eoff.p;
+            PP.hel = d_hel.p; PP.slab = L.slab.p;
+            launch_panel_project(PP, st);
+            launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, st);
         }
     }
     L.have_H = true;

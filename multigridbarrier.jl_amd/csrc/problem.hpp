@@ -37,8 +37,9 @@ struct Level {
     bool planned = false;
     bool selection = false;               // every row of R has at most one entry, equal to 1
     std::vector<int32_t> hHptr, hHcol;
-    DevBuf<int32_t> Hptr, Hcol, cptr, cidx, ecol_ptr, ecols;
-    DevBuf<double> Hval, panels;
+    DevBuf<int32_t> Hptr, Hcol, cptr, cidx, ecol_ptr, ecols, eoff;
+    DevBuf<double> Hval, panels, slab;
+    int64_t slab_doubles = 0;
     int64_t nnz = 0;
     MfSolver solver;
     bool have_H = false, factored = false;

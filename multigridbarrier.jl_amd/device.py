@@ -101,7 +101,7 @@ EXPORTS = [
     "mgbhip_problem_destroy", "mgbhip_problem_set_box", "mgbhip_problem_set_barrier_weights",
     "mgbhip_level_size", "mgbhip_f0", "mgbhip_f1", "mgbhip_f2", "mgbhip_hessian_pattern", "mgbhip_solve",
     "mgbhip_node_barrier", "mgbhip_node_slack", "mgbhip_mgb_core", "mgbhip_matched_t",
-    "mgbhip_default_options", "mgbhip_stage_ms", "mgbhip_reset_stage_timers",
+    "mgbhip_default_options", "mgbhip_stage_ms", "mgbhip_reset_stage_timers", "mgbhip_solver_stats",
 ]
 
 
@@ -145,6 +145,7 @@ def load_library():
     lib.mgbhip_default_options.restype = None
     lib.mgbhip_stage_ms.argtypes = [C.c_void_p, C.c_char_p, _dp, C.POINTER(C.c_int64)]
     lib.mgbhip_reset_stage_timers.argtypes = [C.c_void_p, C.c_int]
+    lib.mgbhip_solver_stats.argtypes = [C.c_void_p, C.c_int32, _dp]
     _LIB = lib
     return lib
 
@@ -400,6 +401,12 @@ class DeviceProblem:
         ms, cnt = C.c_double(), C.c_int64()
         _check(self.lib, self.lib.mgbhip_stage_ms(self.handle, stage.encode(), C.cast(C.byref(ms), _dp), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def solver_stats(self, level: int) -> dict:
+        out = np.zeros(8)
+        _check(self.lib, self.lib.mgbhip_solver_stats(self.handle, level, _ptr(out)))
+        keys = ("fronts", "max_front", "arena_doubles", "factor_flops", "peeled", "tree_levels", "nnz", "unknowns")
+        return dict(zip(keys, out.tolist()))
 
     def close(self):
         if self.handle:

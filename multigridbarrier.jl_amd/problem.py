@@ -74,12 +74,18 @@ def assemble(mg: MultiGrid, dim: Optional[int] = None, state_variables=None, D=N
         D = default_D(dim)
     if x is None:
         x = geom.xflat
+    nx = x.shape[0]
     if g_grid is None:
-        gg = default_g(dim) if g is None else g
-        g_grid = np.stack([np.atleast_1d(np.asarray(gg(xi), dtype=np.float64)) for xi in x], axis=0)
+        if g is None:      # default_g, vectorised over the nodes
+            g_grid = (np.stack([x[:, 0], np.full(nx, 2.0)], axis=1) if dim == 1 else
+                      np.stack([np.sum(x[:, :dim] ** 2, axis=1), np.full(nx, 100.0)], axis=1))
+        else:
+            g_grid = np.stack([np.atleast_1d(np.asarray(g(xi), dtype=np.float64)) for xi in x], axis=0)
     if f_grid is None:
-        ff = default_f(dim) if f is None else f
-        f_grid = np.stack([np.atleast_1d(np.asarray(ff(xi), dtype=np.float64)) for xi in x], axis=0)
+        if f is None:      # default_f
+            f_grid = np.tile(np.array([0.5] + [0.0] * dim + [1.0]), (nx, 1))
+        else:
+            f_grid = np.stack([np.atleast_1d(np.asarray(f(xi), dtype=np.float64)) for xi in x], axis=0)
     if Q is None:
         pval = float(p)
         Q = convex_Euclidian_power(mg, idx=default_idx(dim), p_grid=np.full(x.shape[0], pval))

@@ -1,0 +1,213 @@
+// mf_host.cpp -- ORACLE / TEST INFRASTRUCTURE (not shipped, not linked into libmgbhip.so).
+// A plain host sparse Cholesky that follows the plan produced by the product's symbolic
+// analysis (csrc/mf_analysis.cpp: same scatter lists, relative indices, level order as the
+// device kernels in csrc/mf_numeric.hip).  Two uses: (1) the symbolic analysis is validated
+// on a machine without a GPU against SciPy's SuperLU; (2) it is the direct solver of the
+// CPU baseline in bench.py, standing in for the CHOLMOD call behind the reference's
+// `solve(symmetric(H), g)` (src/utils.jl:142-145) -- SuperLU alone would understate the
+// reference's CPU path by an order of magnitude.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../multigridbarrier.jl_amd/csrc/mf_analysis.hpp"
+#include <map>
+#include <memory>
+
+using namespace mgbhip;
+
+extern "C" int mf_host_solve(int64_t n, const int32_t* rowptr, const int32_t* colidx,
+                             const double* values, const double* b, double* x, int32_t leaf_size,
+                             double* stats /* 8 */) {
+    MfPlan plan;
+    MfOptions opt;
+    if (leaf_size > 0) opt.leaf_size = leaf_size;
+    try {
+        mf_analyze(n, rowptr, colidx, opt, plan);
+    } catch (const std::exception& e) {
+        return -1;
+    }
+    std::vector<double> arena((size_t)plan.arena_doubles, 0.0);
+    std::vector<double> uvec((size_t)plan.uvec_doubles, 0.0);
+    int status = 0;
+    const int32_t nf = (int32_t)plan.fronts.size();
+    // factor: fronts are sorted by level, children strictly earlier
+    for (int32_t i = 0; i < nf; ++i) {
+        const Front& f = plan.fronts[i];
+        double* F = arena.data() + f.F_off;
+        const int32_t m = f.m, k = f.k;
+        for (int32_t t = 0; t < f.a_cnt; ++t) F[plan.a_dst[f.a_off + t]] = values[plan.a_src[f.a_off + t]];
+        for (int32_t c = 0; c < f.nchild; ++c) {
+            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
+            const double* U = arena.data() + ch.F_off;
+            const int32_t mc = ch.m, kc = ch.k;
+            const int32_t* rel = plan.rel.data() + ch.rel_off;
+            for (int32_t j = kc; j < mc; ++j)
+                for (int32_t r = j; r < mc; ++r) F[rel[r - kc] + (int64_t)rel[j - kc] * m] += U[r + (int64_t)j * mc];
+        }
+        for (int32_t j = 0; j < k; ++j) {
+            double d = F[j + (int64_t)j * m];
+            if (!(d > 0)) status = 3;
+            double l = std::sqrt(d);
+            F[j + (int64_t)j * m] = l;
+            for (int32_t r = j + 1; r < m; ++r) F[r + (int64_t)j * m] /= l;
+            for (int32_t c2 = j + 1; c2 < m; ++c2) {
+                double lc = F[c2 + (int64_t)j * m];
+                for (int32_t r = c2; r < m; ++r) F[r + (int64_t)c2 * m] -= F[r + (int64_t)j * m] * lc;
+            }
+        }
+    }
+    // forward
+    std::vector<double> y((size_t)n, 0.0), t;
+    for (int32_t i = 0; i < nf; ++i) {
+        const Front& f = plan.fronts[i];
+        const double* F = arena.data() + f.F_off;
+        const int32_t* idx = plan.front_idx.data() + f.idx_off;
+        const int32_t m = f.m, k = f.k;
+        t.assign(m, 0.0);
+        for (int32_t j = 0; j < k; ++j) t[j] = b[idx[j]];
+        for (int32_t c = 0; c < f.nchild; ++c) {
+            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
+            const int32_t* rel = plan.rel.data() + ch.rel_off;
+            for (int32_t j = 0; j < ch.m - ch.k; ++j) t[rel[j]] += uvec[ch.u_off + j];
+        }
+        for (int32_t j = 0; j < k; ++j) {
+            t[j] /= F[j + (int64_t)j * m];
+            for (int32_t r = j + 1; r < m; ++r) t[r] -= F[r + (int64_t)j * m] * t[j];
+        }
+        for (int32_t j = 0; j < k; ++j) y[idx[j]] = t[j];
+        for (int32_t j = k; j < m; ++j) uvec[f.u_off + j - k] = t[j];
+    }
+    // backward (roots first)
+    for (int32_t i = nf - 1; i >= 0; --i) {
+        const Front& f = plan.fronts[i];
+        const double* F = arena.data() + f.F_off;
+        const int32_t* idx = plan.front_idx.data() + f.idx_off;
+        const int32_t m = f.m, k = f.k;
+        t.assign(m, 0.0);
+        for (int32_t j = 0; j < k; ++j) t[j] = y[idx[j]];
+        for (int32_t j = k; j < m; ++j) t[j] = x[idx[j]];
+        for (int32_t j = k - 1; j >= 0; --j) {
+            double s = t[j];
+            for (int32_t r = j + 1; r < m; ++r) s -= F[r + (int64_t)j * m] * t[r];
+            t[j] = s / F[j + (int64_t)j * m];
+        }
+        for (int32_t j = 0; j < k; ++j) x[idx[j]] = t[j];
+    }
+    if (stats) {
+        stats[0] = (double)nf;
+        stats[1] = (double)plan.max_m;
+        stats[2] = (double)plan.arena_doubles;
+        stats[3] = (double)plan.factor_flops;
+        stats[4] = (double)plan.peeled;
+        stats[5] = (double)plan.peel_rounds;
+        stats[6] = (double)(plan.level_ptr.size() - 1);
+        stats[7] = (double)plan.uvec_doubles;
+    }
+    return status;
+}
+
+
+// ---- cached-plan variant for the CPU baseline: analyze once per pattern, then factor+solve ----
+struct HostSolver {
+    MfPlan plan;
+    std::vector<double> arena, uvec;
+};
+
+extern "C" void* mf_host_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, int32_t leaf_size) {
+    auto* S = new HostSolver();
+    MfOptions opt;
+    if (leaf_size > 0) opt.leaf_size = leaf_size;
+    try {
+        mf_analyze(n, rowptr, colidx, opt, S->plan);
+    } catch (const std::exception&) {
+        delete S;
+        return nullptr;
+    }
+    S->arena.assign((size_t)S->plan.arena_doubles, 0.0);
+    S->uvec.assign((size_t)S->plan.uvec_doubles, 0.0);
+    return S;
+}
+
+extern "C" void mf_host_free(void* h) { delete (HostSolver*)h; }
+
+extern "C" int mf_host_factor_solve(void* h, const double* values, const double* b, double* x) {
+    HostSolver* S = (HostSolver*)h;
+    const MfPlan& plan = S->plan;
+    std::vector<double>& arena = S->arena;
+    std::vector<double>& uvec = S->uvec;
+    std::fill(arena.begin(), arena.end(), 0.0);
+    int status = 0;
+    const int32_t nf = (int32_t)plan.fronts.size();
+    for (int32_t i = 0; i < nf; ++i) {
+        const Front& f = plan.fronts[i];
+        double* F = arena.data() + f.F_off;
+        const int32_t m = f.m, k = f.k;
+        for (int32_t t = 0; t < f.a_cnt; ++t) F[plan.a_dst[f.a_off + t]] = values[plan.a_src[f.a_off + t]];
+        for (int32_t c = 0; c < f.nchild; ++c) {
+            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
+            const double* U = arena.data() + ch.F_off;
+            const int32_t mc = ch.m, kc = ch.k;
+            const int32_t* rel = plan.rel.data() + ch.rel_off;
+            for (int32_t j = kc; j < mc; ++j) {
+                double* Fc = F + (int64_t)rel[j - kc] * m;
+                const double* Uc = U + (int64_t)j * mc;
+                for (int32_t r = j; r < mc; ++r) Fc[rel[r - kc]] += Uc[r];
+            }
+        }
+        for (int32_t j = 0; j < k; ++j) {
+            double* Lj = F + (int64_t)j * m;
+            double d = Lj[j];
+            if (!(d > 0)) status = 3;
+            double l = std::sqrt(d), inv = 1.0 / l;
+            Lj[j] = l;
+            for (int32_t r = j + 1; r < m; ++r) Lj[r] *= inv;
+            for (int32_t c2 = j + 1; c2 < m; ++c2) {
+                const double lc = Lj[c2];
+                if (lc == 0.0) continue;
+                double* Fc = F + (int64_t)c2 * m;
+                for (int32_t r = c2; r < m; ++r) Fc[r] -= Lj[r] * lc;
+            }
+        }
+    }
+    const int64_t n = plan.n;
+    std::vector<double> y((size_t)n, 0.0), t;
+    for (int32_t i = 0; i < nf; ++i) {
+        const Front& f = plan.fronts[i];
+        const double* F = arena.data() + f.F_off;
+        const int32_t* idx = plan.front_idx.data() + f.idx_off;
+        const int32_t m = f.m, k = f.k;
+        t.assign(m, 0.0);
+        for (int32_t j = 0; j < k; ++j) t[j] = b[idx[j]];
+        for (int32_t c = 0; c < f.nchild; ++c) {
+            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
+            const int32_t* rel = plan.rel.data() + ch.rel_off;
+            for (int32_t j = 0; j < ch.m - ch.k; ++j) t[rel[j]] += uvec[ch.u_off + j];
+        }
+        for (int32_t j = 0; j < k; ++j) {
+            t[j] /= F[j + (int64_t)j * m];
+            const double* Lj = F + (int64_t)j * m;
+            for (int32_t r = j + 1; r < m; ++r) t[r] -= Lj[r] * t[j];
+        }
+        for (int32_t j = 0; j < k; ++j) y[idx[j]] = t[j];
+        for (int32_t j = k; j < m; ++j) uvec[f.u_off + j - k] = t[j];
+    }
+    for (int32_t i = nf - 1; i >= 0; --i) {
+        const Front& f = plan.fronts[i];
+        const double* F = arena.data() + f.F_off;
+        const int32_t* idx = plan.front_idx.data() + f.idx_off;
+        const int32_t m = f.m, k = f.k;
+        t.assign(m, 0.0);
+        for (int32_t j = 0; j < k; ++j) t[j] = y[idx[j]];
+        for (int32_t j = k; j < m; ++j) t[j] = x[idx[j]];
+        for (int32_t j = k - 1; j >= 0; --j) {
+            const double* Lj = F + (int64_t)j * m;
+            double s = t[j];
+            for (int32_t r = j + 1; r < m; ++r) s -= Lj[r] * t[r];
+            t[j] = s / Lj[j];
+        }
+        for (int32_t j = 0; j < k; ++j) x[idx[j]] = t[j];
+    }
+    return status;
+}

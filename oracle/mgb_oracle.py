@@ -322,6 +322,62 @@ def solve_symmetric(H, g):
     return np.linalg.solve(Hs, g)
 
 
+class MfHostSolver:
+    """`solve(symmetric(H), g)` through the host multifrontal Cholesky of oracle/csrc/mf_host.cpp
+    (analysis cached per sparsity pattern, like CHOLMOD's symbolic reuse).  Falls back to
+    SuperLU when the matrix is not numerically SPD (the reference falls back to LDLt/LU)."""
+
+    def __init__(self):
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libmf_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle`")
+        self.C = C
+        self.lib = C.CDLL(path)
+        self.lib.mf_host_analyze.restype = C.c_void_p
+        self.lib.mf_host_analyze.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
+        self.lib.mf_host_factor_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.mf_host_free.argtypes = [C.c_void_p]
+        self.cache = {}
+
+    def __call__(self, H, g):
+        if not sp.issparse(H):
+            return solve_symmetric(H, g)
+        A = sp.csr_matrix(H)
+        A.sort_indices()
+        key = (A.shape[0], A.nnz, hash(A.indptr.tobytes()), hash(A.indices.tobytes()))
+        ent = self.cache.get(key)
+        if ent is None:
+            ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
+            ii = np.ascontiguousarray(A.indices, dtype=np.int32)
+            h = self.lib.mf_host_analyze(A.shape[0], ip.ctypes.data, ii.ctypes.data, 0)
+            if not h:
+                return solve_symmetric(H, g)
+            ent = (h, ip, ii)
+            self.cache[key] = ent
+        v = np.ascontiguousarray(A.data, dtype=np.float64)
+        b = np.ascontiguousarray(g, dtype=np.float64)
+        x = np.zeros_like(b)
+        rc = self.lib.mf_host_factor_solve(ent[0], v.ctypes.data, b.ctypes.data, x.ctypes.data)
+        if rc != 0:
+            return solve_symmetric(H, g)
+        return x
+
+    def close(self):
+        for h, _, _ in self.cache.values():
+            self.lib.mf_host_free(h)
+        self.cache = {}
+
+
+_SOLVER = [solve_symmetric]
+
+
+def set_solver(kind: str):
+    """'splu' (SciPy SuperLU, the default) or 'mf' (host multifrontal Cholesky)."""
+    _SOLVER[0] = solve_symmetric if kind == "splu" else MfHostSolver()
+
+
 # ---------------------------------------------------------------------------
 # Newton, line searches, stopping rules (src/newton.jl)
 # ---------------------------------------------------------------------------
@@ -421,13 +477,15 @@ def stopping_inexact(lambda_tol, theta):
     return lambda ymin, ynext, gmin, gnext, n, ndecmin, ndec: bool(ndec < lambda_tol or ex(ymin, ynext, gmin, gnext, n, ndecmin, ndec))
 
 
-def newton(F0, F1, F2, x, maxit=10000, stopping_criterion=None, line_search=None, solve=solve_symmetric,
+def newton(F0, F1, F2, x, maxit=10000, stopping_criterion=None, line_search=None, solve=None,
            stats=None):
     """src/newton.jl:227-287."""
     if stopping_criterion is None:
         stopping_criterion = stopping_exact(0.1)
     if line_search is None:
         line_search = linesearch_illinois()
+    if solve is None:
+        solve = _SOLVER[0]
     if not np.all(np.isfinite(x)):
         raise FloatingPointError("newton: initial point has non-finite entries")
     y = F0(x)
@@ -449,6 +507,9 @@ def newton(F0, F1, F2, x, maxit=10000, stopping_criterion=None, line_search=None
         n = solve(H, g)
         if stats is not None:
             stats["solve_s"] = stats.get("solve_s", 0.0) + time.perf_counter() - t0
+            stats["newton_its"] = stats.get("newton_its", 0) + 1
+            if "deadline" in stats and time.perf_counter() > stats["deadline"]:
+                raise TimeoutError("oracle time budget exhausted")
         if not np.all(np.isfinite(n)):
             raise FloatingPointError("newton: Newton direction has non-finite entries")
         inc = float(np.dot(g, n))
@@ -596,8 +657,8 @@ def _matched_t(Q, M, z, c, t_default, barrier_weights=None):
     gphi = B.f1(s0, w, c0, R, D, z)
     gc = B.f1(s0, w, c, R, D, z) - gphi
     H = B.f2(s0, w, c, R, D, z)
-    nphi = solve_symmetric(H, gphi)
-    nc = solve_symmetric(H, gc)
+    nphi = _SOLVER[0](H, gphi)
+    nc = _SOLVER[0](H, gc)
     d = float(np.dot(gc, nc))
     b = float(np.dot(gphi, nc) + np.dot(gc, nphi))
     if not d > 0:

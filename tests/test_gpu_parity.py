@@ -1,0 +1,254 @@
+"""GPU parity tests (-m gpu): every primitive of the hot path, through the C ABI, against the
+oracle on identical seeded inputs; end-to-end solves against the reference's golden vectors
+and against the oracle; size-independent properties at BASELINE config-2 size.
+
+Tolerances: north_star asks for 1e-10 relative per kernel (fp64); the end-to-end bar is the
+reference's own cross-backend criterion max|z_cpu - z_dev| < 1e-8 (test/test_cuda.jl:51)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import mgb_amd as m
+from helpers import build_case, gold_z, lower_bound_problem, stacked
+from oracle import mgb_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KERNEL_RTOL = 1e-10
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _device(prob):
+    from mgb_amd.device import DeviceMGBProblem
+    return DeviceMGBProblem(prob)
+
+
+def _check_primitives(P, Mo, Q, c, z0, rng, scale=1e-3, solve=True):
+    B = O.Barrier(Q)
+    for J in range(len(Mo.R_fine)):
+        R = Mo.R_fine[J]
+        s = scale * rng.standard_normal(R.shape[1])
+        y_o = B.f0(s, Mo.w, c, R, Mo.D_fine, z0)
+        g_o = B.f1(s, Mo.w, c, R, Mo.D_fine, z0)
+        H_o = sp.csr_matrix(B.f2(s, Mo.w, c, R, Mo.D_fine, z0))
+        assert np.isfinite(y_o)
+        assert abs(P.f0(J, s, c, z0) - y_o) <= KERNEL_RTOL * abs(y_o)
+        g_d = P.f1(J, s, c, z0)
+        assert rel(g_d, g_o) <= KERNEL_RTOL
+        H_d = P.f2(J, s, c, z0)
+        assert abs(H_d - H_o).max() <= KERNEL_RTOL * abs(H_o).max()
+        assert abs(H_d - H_d.T).max() <= 1e-13 * abs(H_d).max()
+        if solve:
+            x_d = P.solve(J, g_d)
+            x_o = O.solve_symmetric(sp.csc_matrix(H_o), g_o)
+            assert rel(x_d, x_o) <= 1e-8          # conditioning-limited; the residual check is tight
+            assert np.linalg.norm(H_d @ x_d - g_d) <= 1e-9 * np.linalg.norm(g_d)
+
+
+@pytest.mark.parametrize("spec", [
+    ("fem2d_P2", dict(L=3), 1.5), ("fem2d_P2", dict(L=3), 1.0), ("fem2d_P2", dict(L=2), 4.0),
+    ("fem1d", dict(nodes=9), 2.0), ("fem3d", dict(L=2, k=1), 1.5), ("fem2d_Q2", dict(L=2), 1.5),
+    ("spectral1d", dict(n=6), 1.5), ("spectral2d", dict(n=4), 1.0)])
+def test_barrier_closures_and_solve_match_oracle(spec):
+    kind, kw, p = spec
+    if kind == "fem2d_P2":
+        geom = m.subdivide(m.fem2d_P2(), kw["L"])
+    elif kind == "fem1d":
+        geom = m.fem1d(nodes=np.linspace(-1, 1, kw["nodes"]))
+    elif kind == "fem3d":
+        geom = m.subdivide(m.fem3d(k=kw["k"]), kw["L"])
+    elif kind == "fem2d_Q2":
+        geom = m.subdivide(m.fem2d(k=2), kw["L"])
+    elif kind == "spectral1d":
+        geom = m.spectral1d(n=kw["n"])
+    else:
+        geom = m.spectral2d(n=kw["n"])
+    prob = m.assemble(m.amg(geom), p=p)
+    D = _device(prob)
+    try:
+        _check_primitives(D.main, O.OracleAMG(prob.M[0]), prob.Q, 0.1 * prob.f, stacked(prob.g),
+                          np.random.default_rng(7))
+    finally:
+        D.close()
+
+
+def test_phase1_barrier_and_piecewise_linear_cones_match_oracle():
+    # two-sided obstacle pattern (reference: src/Zoo/two_sided_obstacle.jl:23-49): EP(p=2) intersect box on u
+    mg = m.amg(m.subdivide(m.fem2d_P2(), 2))
+    Q = m.intersect(mg, m.convex_Euclidian_power(mg, idx=(2, 3, 4), p_grid=np.full(mg.geometry.w.size, 2.0)),
+                    m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[1.0], [-1.0]]),
+                                    b=lambda x: np.array([0.1 + 0.05 * x[0], 1.0])))
+    n = mg.geometry.w.size
+    prob = m.assemble(mg, Q=Q, f_grid=np.tile([2.0, 0, 0, 0.5], (n, 1)), g_grid=np.tile([0.0, 10.0], (n, 1)))
+    D = _device(prob)
+    rng = np.random.default_rng(3)
+    try:
+        z0 = stacked(prob.g)
+        _check_primitives(D.main, O.OracleAMG(prob.M[0]), prob.Q, 0.1 * prob.f, z0, rng, scale=1e-4)
+        # node maps
+        Mo = O.OracleAMG(prob.M[0])
+        F_d, Dz_d = D.main.node_barrier(z0, want_Dz=True)
+        Dz_o = O.apply_D(Mo.D_fine, z0)
+        assert rel(Dz_d, Dz_o) <= 1e-13
+        assert rel(F_d, O.convex_eval(prob.Q, Dz_o, 0)) <= 1e-12
+        assert rel(D.main.node_slack(z0), O.convex_slack(prob.Q, Dz_o)) <= 1e-12
+        # phase-I image: cobarrier + box (src/mgb.jl:217-287)
+        feas = D.feasibility
+        M2 = O.OracleAMG(prob.M[1])
+        nD = len(prob.M[0].D_fine)
+        feas.set_box(30.0, 40.0)
+        Qf = O.FeasConvex(prob.Q, 30.0, 40.0, nD + 1)
+        z1 = np.concatenate([z0, np.full(n, 3.0)])
+        c1 = np.zeros((n, nD + 1 + 2)); c1[:, nD] = 1.0
+        _check_primitives(feas, M2, Qf, c1, z1, rng, scale=1e-4)
+    finally:
+        D.close()
+
+
+def test_masked_barrier_weights_path():
+    # pure P2 has zero corner weights -> masked barrier (src/convex.jl:213-257)
+    geom = m.subdivide(m.fem2d_P2(bubble=False), 2)
+    prob = m.assemble(m.amg(geom), p=1.5)
+    from mgb_amd.solve import _barrier_weights
+    bw = _barrier_weights(prob.M[0].w, prob.M[0].w != 0)
+    assert bw is not None
+    D = _device(prob)
+    try:
+        D.main.set_barrier_weights(bw)
+        Mo = O.OracleAMG(prob.M[0])
+        B = O.Barrier(prob.Q, bw)
+        z0, c = stacked(prob.g), 0.1 * prob.f
+        rng = np.random.default_rng(5)
+        for J in range(len(Mo.R_fine)):
+            R = Mo.R_fine[J]
+            s = 1e-3 * rng.standard_normal(R.shape[1])
+            assert abs(D.main.f0(J, s, c, z0) - B.f0(s, Mo.w, c, R, Mo.D_fine, z0)) <= 1e-10 * abs(B.f0(s, Mo.w, c, R, Mo.D_fine, z0))
+            assert rel(D.main.f1(J, s, c, z0), B.f1(s, Mo.w, c, R, Mo.D_fine, z0)) <= KERNEL_RTOL
+            Ho = sp.csr_matrix(B.f2(s, Mo.w, c, R, Mo.D_fine, z0))
+            assert abs(D.main.f2(J, s, c, z0) - Ho).max() <= KERNEL_RTOL * abs(Ho).max()
+    finally:
+        D.close()
+
+
+def test_infeasible_point_returns_nonfinite_not_error():
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 2)), p=1.5)
+    D = _device(prob)
+    try:
+        z0 = stacked(prob.g)
+        z0[prob.M[0].w.size:] = -1.0          # slack below the cone: Log -> -Inf protocol (src/utils.jl:14)
+        J = len(D.main.level_sizes) - 1
+        y = D.main.f0(J, np.zeros(D.main.level_sizes[J]), 0.1 * prob.f, z0)
+        assert not np.isfinite(y)
+        assert not np.all(np.isfinite(D.main.node_barrier(z0)))
+    finally:
+        D.close()
+
+
+GOLD = ["fem1d_3nodes_p1", "fem2d_P2_L1_p1", "spectral1d_n5_p1", "spectral2d_n5_p1", "fem1d_5nodes_p1",
+        "fem1d_5nodes_p1.5", "fem2d_P2_L2_p1", "fem2d_P2_L2_p1.5", "fem3d_k1_L2_p1", "fem3d_k1_L2_p1.5"]
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_mgb_solve_reproduces_reference_golden(golden, name):
+    c = golden[name]
+    sol = m.mgb_solve(build_case(c))
+    assert np.linalg.norm(sol.z - gold_z(c)) < c["tol"]
+    assert "mgb_solve: device = HIPDevice" in sol.log
+
+
+@pytest.mark.parametrize("L,p", [(3, 1.0), (4, 1.5), (4, 1.0)])
+def test_mgb_solve_matches_oracle_end_to_end(L, p):
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), L)), p=p)
+    sol = m.mgb_solve(prob)
+    so = O.mgb_solve(prob)
+    assert np.abs(sol.z - so["z"]).max() < 1e-8          # the reference's CPU-vs-CUDA bar (test/test_cuda.jl:51)
+
+
+def test_illinois_line_search_and_exact_stopping():
+    prob = m.assemble(m.amg(m.fem1d(nodes=np.linspace(-1, 1, 9))), p=1.5)
+    sol = m.mgb_solve(prob, line_search=("illinois", 0.5), stopping_criterion=("exact", 0.1), finalize=False, tol=1e-6)
+    so = O.mgb_solve(prob, line_search=O.linesearch_illinois(), stopping_criterion=O.stopping_exact(0.1),
+                     finalize=False, tol=1e-6)
+    assert np.abs(sol.z - so["z"]).max() < 1e-6
+
+
+def test_feasibility_phase_on_device():
+    # test/test_feasibility.jl:24-87 through the HIP path
+    sol = m.mgb_solve(lower_bound_problem(50.0))
+    assert sol.SOL_feasibility is not None and np.abs(sol.z - 50.0).max() < 1e-3
+    assert "bounding box R=100" in sol.log
+    sol = m.mgb_solve(lower_bound_problem(-50.0))
+    assert sol.SOL_feasibility is None and np.abs(sol.z + 50.0).max() < 1e-3
+    with pytest.raises(m.MGBConvergenceFailure) as ei:
+        m.mgb_solve(lower_bound_problem(1.0e6), feasibility_Rmax=1000.0)
+    assert ei.value.code == "feasibility_Rmax"
+    mg = m.amg(m.fem1d(nodes=np.linspace(-1, 1, 5)))
+    Q = m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[1.0], [-1.0]]), b=lambda x: np.array([-1.0, 0.0]))
+    prob = m.assemble(mg, state_variables=[("u", "full")], D=[("u", "id")], f=lambda x: np.array([1.0]),
+                      g=lambda x: np.array([0.0]), Q=Q)
+    with pytest.raises(m.MGBConvergenceFailure) as ei:
+        m.mgb_solve(prob)
+    assert ei.value.code == "infeasible"
+
+
+def test_phase1_then_main_matches_oracle():
+    # infeasible start (s = 0.5 < |grad g|): phase I with the box barrier, _matched_t handoff, main ramp
+    mg = m.amg(m.subdivide(m.fem2d_P2(), 2))
+    x = mg.geometry.xflat
+    prob = m.assemble(mg, p=1.0, g_grid=np.stack([np.sum(x ** 2, axis=1), np.full(x.shape[0], 0.5)], axis=1))
+    sol = m.mgb_solve(prob)
+    so = O.mgb_solve(prob)
+    assert sol.SOL_feasibility is not None and so["SOL_feasibility"] is not None
+    assert abs(sol.SOL_main["ts"][0] - so["SOL_main"]["ts"][0]) <= 1e-8 * so["SOL_main"]["ts"][0]   # _matched_t
+    assert np.abs(sol.z - so["z"]).max() < 1e-6
+
+
+def test_fem3d_p4_config4_family_matches_oracle():
+    prob = m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 3)), p=4.0)
+    sol = m.mgb_solve(prob)
+    so = O.mgb_solve(prob)
+    assert np.abs(sol.z - so["z"]).max() < 1e-6
+
+
+def test_config2_size_properties_and_determinism():
+    """fem2d_P2 p=1.5 L=7 (BASELINE configs[1]): size-independent properties instead of an oracle run."""
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 7)), p=1.5)
+    D = _device(prob)
+    try:
+        P = D.main
+        J = len(P.level_sizes) - 1
+        rng = np.random.default_rng(11)
+        z0, c = stacked(prob.g), 0.1 * prob.f
+        s = 1e-4 * rng.standard_normal(P.level_sizes[J])
+        d = rng.standard_normal(P.level_sizes[J])
+        g = P.f1(J, s, c, z0)
+        H = P.f2(J, s, c, z0)
+        assert abs(H - H.T).max() <= 1e-13 * abs(H).max()                   # symmetry
+        h = 1e-6
+        fd = (P.f0(J, s + h * d, c, z0) - P.f0(J, s - h * d, c, z0)) / (2 * h)
+        assert abs(fd - g @ d) <= 1e-6 * max(abs(g @ d), 1e-12)             # f1 is the gradient of f0
+        gd = (P.f1(J, s + h * d, c, z0) - P.f1(J, s - h * d, c, z0)) / (2 * h)
+        assert rel(gd, H @ d) <= 1e-5                                        # f2 is the Jacobian of f1
+        x = P.solve(J, g)
+        assert np.linalg.norm(H @ x - g) <= 1e-9 * np.linalg.norm(g)        # direct solve residual
+        assert g @ x > 0                                                     # SPD: positive Newton decrement
+        # f1 is affine in c (used by _matched_t, src/mgb.jl:316-317)
+        g0 = P.f1(J, s, 0 * c, z0)
+        g2 = P.f1(J, s, 2 * c, z0)
+        assert rel(g2 - g0, 2 * (g - g0)) <= 1e-12
+        # bitwise reproducibility of the atomic-free assembly and of the factorization
+        H2 = P.f2(J, s, c, z0)
+        assert np.array_equal(H.data, H2.data)
+        assert np.array_equal(x, P.solve(J, g))
+    finally:
+        D.close()
+    sol1 = m.mgb_solve(prob)
+    sol2 = m.mgb_solve(prob)
+    assert np.array_equal(sol1.z, sol2.z)
+    assert int(sol1.SOL_main["its"].sum()) == int(sol2.SOL_main["its"].sum())
+    zb = sol1.z[:, 0]
+    bnd = np.array([v + e * 7 for (v, e) in m.find_boundary(prob.geometry)])
+    assert np.abs(zb[bnd] - prob.g[bnd, 0]).max() < 1e-12                    # Dirichlet data preserved exactly

@@ -1,0 +1,114 @@
+"""The oracle is pinned by the reference's own golden vectors and known-answer tests
+(reference: test/runtests.jl:13-32, test/test_algebraic.jl:38-69, test/test_algebraic_coverage.jl,
+test/test_feasibility.jl).  CPU only."""
+import numpy as np
+import pytest
+
+import mgb_amd as m
+from helpers import build_case, gold_z, lower_bound_problem
+from oracle import mgb_oracle as O
+
+CASES = ["fem1d_3nodes_p1", "fem2d_P2_L1_p1", "spectral1d_n5_p1", "spectral2d_n5_p1", "fem1d_5nodes_p1",
+         "fem1d_5nodes_p1.5", "fem2d_P2_L2_p1", "fem2d_P2_L2_p1.5", "fem3d_k1_L2_p1", "fem3d_k1_L2_p1.5"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_reference_golden(golden, name):
+    c = golden[name]
+    sol = O.mgb_solve(build_case(c))
+    assert np.linalg.norm(sol["z"] - gold_z(c)) < c["tol"]
+
+
+def test_linear_cobarrier_hessian_known_answer():
+    # test/test_algebraic_coverage.jl:48-59: rectangular linear cobarrier Hessian == B' diag(1/F^2) B
+    mg = m.amg(m.fem1d(nodes=np.linspace(-1, 1, 3)))
+    A = np.array([[1.0, 2.0], [0.5, -1.0], [3.0, 1.0]])
+    b = np.array([4.0, 5.0, 6.0])
+    Q = m.convex_linear(mg, idx=(1, 2), A=lambda x: A, b=lambda x: b)
+    n = mg.geometry.w.size
+    yhat = np.tile(np.array([0.3, -0.2, 0.7]), (n, 1))
+    H = O.convex_eval(Q, yhat, 2, co=True)[0]
+    Bm = np.hstack([A, np.ones((3, 1))])
+    F = Bm @ yhat[0] + b
+    assert np.allclose(H, Bm.T @ np.diag(1 / F ** 2) @ Bm, atol=1e-13)
+    G = O.convex_eval(Q, yhat, 1, co=True)[0]
+    assert np.allclose(G, -Bm.T @ (1 / F), atol=1e-13)
+
+
+def test_ep_gradient_hessian_consistency():
+    mg = m.amg(m.subdivide(m.fem2d_P2(), 1))
+    n = mg.geometry.w.size
+    rng = np.random.default_rng(0)
+    for p in (1.0, 1.5, 2.0, 4.0):
+        Q = m.convex_Euclidian_power(mg, idx=(2, 3, 4), p_grid=np.full(n, p))
+        y = np.column_stack([rng.standard_normal(n), 0.3 * rng.standard_normal((n, 2)), 5 + rng.random(n)])
+        G = O.convex_eval(Q, y, 1)
+        H = O.convex_eval(Q, y, 2)
+        h = 1e-6
+        for k in range(4):
+            e = np.zeros(4); e[k] = h
+            fd = (O.convex_eval(Q, y + e, 0) - O.convex_eval(Q, y - e, 0)) / (2 * h)
+            assert np.allclose(G[:, k], fd, rtol=1e-6, atol=1e-7)
+            fdg = (O.convex_eval(Q, y + e, 1) - O.convex_eval(Q, y - e, 1)) / (2 * h)
+            assert np.allclose(H[:, :, k], fdg, rtol=1e-5, atol=1e-6)
+
+
+def test_illinois_and_newton_contracts():
+    # test/test_algebraic_coverage.jl:76-97
+    assert abs(O.illinois(lambda x: x * x - 2, 0.0, 2.0) - np.sqrt(2)) < 1e-12
+    A = np.array([[2.0, 0.5], [0.5, 1.0]])
+    b = np.array([1.0, -1.0])
+    sol = O.newton(lambda x: 0.5 * x @ A @ x - b @ x, lambda x: A @ x - b, lambda x: A, np.zeros(2),
+                   line_search=O.linesearch_backtracking(), solve=lambda H, g: np.linalg.solve(H, g))
+    assert sol["k"] <= 2 and sol["converged"] and np.allclose(sol["x"], np.linalg.solve(A, b))
+
+
+def test_line_search_survives_throwing_objective():
+    # test/test_algebraic_coverage.jl:99-117: a trial that raises is rejected, the step shrinks
+    calls = []
+
+    def F0(x):
+        calls.append(float(x[0]))
+        if x[0] < -0.5:
+            raise ValueError("outside the domain")
+        return float(x[0] ** 2)
+
+    ls = O.linesearch_backtracking()
+    xn, yn, gn = ls(np.array([1.0]), 1.0, np.array([2.0]), np.array([2.0]), F0, lambda x: 2 * x)
+    assert xn[0] >= -0.5 and yn <= 1.0
+
+
+def test_feasibility_phase_behaviours():
+    # test/test_feasibility.jl:24-87
+    sol = O.mgb_solve(lower_bound_problem(50.0))
+    assert sol["SOL_feasibility"] is not None and np.abs(sol["z"] - 50.0).max() < 1e-3
+    assert "bounding box R=100" in sol["log"]
+    sol = O.mgb_solve(lower_bound_problem(-50.0))
+    assert sol["SOL_feasibility"] is None and np.abs(sol["z"] + 50.0).max() < 1e-3
+    with pytest.raises(O.MGBConvergenceFailure) as ei:
+        O.mgb_solve(lower_bound_problem(1.0e6), feasibility_Rmax=1000.0)
+    assert ei.value.code == "feasibility_Rmax"
+    mg = m.amg(m.fem1d(nodes=np.linspace(-1, 1, 5)))
+    Q = m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[1.0], [-1.0]]), b=lambda x: np.array([-1.0, 0.0]))
+    prob = m.assemble(mg, state_variables=[("u", "full")], D=[("u", "id")], f=lambda x: np.array([1.0]),
+                      g=lambda x: np.array([0.0]), Q=Q)
+    with pytest.raises(O.MGBConvergenceFailure) as ei:
+        O.mgb_solve(prob)
+    assert ei.value.code == "infeasible" and "inside the bounding box" in ei.value.message
+
+
+def test_host_multifrontal_matches_superlu():
+    import scipy.sparse as sp
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 4)), p=1.0)
+    M = O.OracleAMG(prob.M[0])
+    B = O.Barrier(prob.Q)
+    z0 = np.ascontiguousarray(prob.g.T).reshape(-1)
+    mf = O.MfHostSolver()
+    rng = np.random.default_rng(0)
+    for J in range(len(M.R_fine)):
+        R = M.R_fine[J]
+        H = B.f2(np.zeros(R.shape[1]), M.w, 0.1 * prob.f, R, M.D_fine, z0)
+        g = rng.standard_normal(R.shape[1])
+        x1, x2 = mf(H, g), O.solve_symmetric(H, g)
+        assert np.linalg.norm(x1 - x2) <= 1e-10 * np.linalg.norm(x2)
+    mf.close()

@@ -1,0 +1,87 @@
+"""Setup layer (CPU): element tables, operators, hierarchy shapes (reference tests:
+test/test_pure_p2.jl:28-51, test/test_tensorfem.jl:32-89, test/test_mixed_bc.jl)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import mgb_amd as m
+from mgb_amd.fem2d_p2 import reference_triangle
+
+# values the reference tabulates (src/fem2d_P2.jl:83-96), as data: 12*dx, 12*dy, 60*w
+DX12 = np.array([[36, 0, 0, 0, 12, -48, 0], [3, 60, -9, 12, 3, 12, -81], [-12, 48, 0, -48, 12, 0, 0],
+                 [-3, -12, 9, -60, -3, -12, 81], [-12, 0, 0, 0, -36, 48, 0], [12, 0, 0, 0, -12, 0, 0],
+                 [4, 16, 0, -16, -4, 0, 0]], dtype=float)
+DY12 = np.array([[0, 48, -12, 0, 12, -48, 0], [-9, 60, 3, 12, 3, 12, -81], [0, 0, 36, -48, 12, 0, 0],
+                 [0, 0, 12, 0, -12, 0, 0], [0, 0, -12, 48, -36, 0, 0], [9, -12, -3, -12, -3, -60, 81],
+                 [0, 16, 4, 0, -4, -16, 0]], dtype=float)
+
+
+def test_reference_triangle_tables_match_reference():
+    R = reference_triangle(True)
+    assert np.allclose(R["dx"] * 12, DX12, atol=1e-12)
+    assert np.allclose(R["dy"] * 12, DY12, atol=1e-12)
+    assert np.allclose(R["w"] * 60, [3, 8, 3, 8, 3, 8, 27], atol=1e-12)
+    R6 = reference_triangle(False)
+    assert np.allclose(R6["w"] * 3, [0, 1, 0, 1, 0, 1], atol=1e-14)      # zero corner weights
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_p2_operators_exact_on_quadratics(L):
+    g = m.subdivide(m.fem2d_P2(), L)
+    x, y = g.xflat[:, 0], g.xflat[:, 1]
+    u = 1 + 2 * x - y + 0.5 * x * x - 3 * x * y + 2 * y * y
+    assert np.allclose(g.operators["dx"].matvec(u), 2 + x - 3 * y, atol=1e-11)
+    assert np.allclose(g.operators["dy"].matvec(u), -1 - 3 * x + 4 * y, atol=1e-11)
+    assert np.isclose(g.w.sum(), 8.0)                   # the reference's weights sum to 2 * area
+    assert np.isclose((g.w * u).sum() / 2, 4 + 4 * 0.5 / 3 + 4 * 2 / 3, atol=1e-10)   # exact quadrature of u
+
+
+def test_node_counts_match_reference_bench_table():
+    # bench.md:18-21 of the reference: 896 / 3584 / 14336 / 57344 nodes at L = 4..7
+    for L, n in ((4, 896), (5, 3584)):
+        assert m.subdivide(m.fem2d_P2(), L).w.size == n
+
+
+def test_tensorfem_derivative_and_quadrature():
+    for d, geom in ((1, m.fem1d(nodes=np.linspace(-1, 1, 5), k=2)), (2, m.subdivide(m.fem2d(k=2), 2)),
+                    (3, m.subdivide(m.fem3d(k=1), 2))):
+        x = geom.xflat
+        u = 1 + x[:, 0] + (x[:, 0] ** 2 if geom.discretization.k >= 2 else 0)
+        du = 1 + (2 * x[:, 0] if geom.discretization.k >= 2 else 0)
+        assert np.allclose(geom.operators["dx"].matvec(u), du, atol=1e-9)
+        assert np.isclose(geom.w.sum(), 2.0 ** d)
+
+
+def test_hierarchy_shapes_and_embeddings():
+    geom = m.subdivide(m.fem2d_P2(), 3)
+    mg = m.amg(geom)
+    n = geom.w.size
+    Rd, Rf, Ru = mg.R["dirichlet"], mg.R["full"], mg.R["uniform"]
+    assert len(Rd) == len(Rf) == len(Ru)
+    fine = sp.csr_matrix(Rd[-1])
+    assert fine.shape[0] == n and set(np.unique(fine.data)) == {1.0} and fine.getnnz(axis=1).max() == 1
+    assert (sp.csr_matrix(Rf[-1]) != sp.identity(n)).nnz == 0
+    for R in Ru:                                         # :uniform lifts to constants at every level
+        assert np.allclose(sp.csr_matrix(R).toarray(), 1.0, atol=1e-12)
+    # every coarse dirichlet space vanishes on the Dirichlet nodes (masking, src/multigrid.jl:98-102)
+    bd = {v + e * 7 for (v, e) in m.find_boundary(geom)}
+    for R in Rd:
+        R = sp.csr_matrix(R)
+        assert abs(R[sorted(bd)]).sum() == 0
+    prob = m.assemble(mg, p=1.5)
+    assert prob.M[0].R_fine[-1].shape == (2 * n, fine.shape[1] + n)
+    assert len(prob.M[1].D_fine) == 4 + 1 + 2           # user rows, slack id, one id per component
+
+
+def test_fine_unknown_count_config2():
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 5)), p=1.5)
+    n = prob.M[0].w.size
+    assert prob.M[0].R_fine[-1].shape[1] == 1473 + n     # continuous zero-trace P2+bubble + broken slack
+
+
+def test_convex_validation():
+    mg = m.amg(m.fem1d(nodes=np.linspace(-1, 1, 3)))
+    with pytest.raises(ValueError):
+        m.assemble(mg, Q=m.convex_Euclidian_power(mg, idx=(2, 3, 4)))        # indexes row 4 of a 3-row D
+    Q = m.intersect(mg, m.convex_Euclidian_power(mg, idx=(2, 3)), m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[1.0], [-1.0]]), b=lambda x: np.array([2.0, 2.0])))
+    assert len(Q.pieces) == 2 and Q.select is None
