@@ -4,6 +4,8 @@
 // _matched_t (src/mgb.jl:307-330).  Vectors never leave the device; the host sees only the
 // scalars the reference's control flow branches on (objective, decrement, norms, flags).
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -16,6 +18,14 @@ using namespace mgbhip;
 namespace {
 
 constexpr double EPS = std::numeric_limits<double>::epsilon();
+
+// MGBHIP_DEBUG=1 prints the scalars the Newton control flow branches on (the reference's
+// @mgblog lines, src/newton.jl:256) to stderr.
+bool debug_on() {
+    static const bool on = [] { const char* e = getenv("MGBHIP_DEBUG"); return e && e[0] == '1'; }();
+    return on;
+}
+#define DBG(...) do { if (debug_on()) { fprintf(stderr, __VA_ARGS__); } } while (0)
 
 struct Stop {       // stopping_exact / stopping_inexact
     double lambda_tol;   // < 0: exact only
@@ -177,6 +187,7 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         const int fstatus = L.solver.status(st);
         P->cnt.solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (fstatus != MGBHIP_OK) {
+            DBG("newton[lev %d] k=%d: Cholesky met a non-positive pivot (y=%.17g |g|=%.6e)\n", C.level, k, y, gnorm);
             // H numerically not SPD: the reference's `\` would fall back to LDLt/LU and then
             // either report lambda^2 <= 0 or throw; both end this Newton attempt unconverged.
             converged = false;
@@ -185,6 +196,7 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         VecStats ns = vec_stats(P, P->d_nv.p, C.m);
         if (ns.bad != 0.0 || !std::isfinite(ns.sumsq)) throw InvalidArgument("newton: Newton direction has non-finite entries");
         const double inc = dev_dot(P, P->d_g.p, P->d_nv.p, C.m);
+        DBG("newton[lev %d] k=%d y=%.17g |g|=%.6e lambda^2=%.6e\n", C.level, k, y, gnorm, inc);
         if (inc <= 0) {
             converged = std::fabs(inc) <= EPS * std::fmax(std::fabs(y), 1.0);   // src/newton.jl:257-271
             break;
@@ -207,6 +219,7 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         ymin = std::fmin(ymin, y);
         incmin = std::fmin(inc, incmin);
     }
+    DBG("newton[lev %d] done k=%d converged=%d y=%.17g\n", C.level, k, (int)converged, y);
     R.k = k;
     R.converged = converged;
     R.y = y;

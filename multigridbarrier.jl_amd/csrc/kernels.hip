@@ -329,7 +329,14 @@ __global__ __launch_bounds__(256) void step_kernel(const double* __restrict__ x,
         xn[i] = v;
         m = (v != xi);
     }
-    if (__any(m) && (threadIdx.x & 63) == 0) atomicOr(moved, 1);
+    // one store per workgroup at most, and only when something moved (atomics on one word
+    // from every wave serialise at the memory side)
+    __shared__ int any_moved;
+    if (threadIdx.x == 0) any_moved = 0;
+    __syncthreads();
+    if (m) any_moved = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && any_moved) *moved = 1;
 }
 
 __global__ __launch_bounds__(256) void scale_copy_kernel(const double* __restrict__ src, double alpha,

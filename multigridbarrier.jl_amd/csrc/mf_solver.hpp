@@ -17,7 +17,8 @@ struct FrontDev {
 
 struct MfLaunch {          // one kernel launch: a contiguous range of fronts of one size class
     int32_t first, count;
-    int32_t cls;           // LDS working size (0 = global-memory path)
+    int32_t cls;           // LDS working size (0 = large-front multi-workgroup path)
+    int32_t max_m, max_k;  // largest front / pivot block in the range
 };
 
 class MfSolver {
