@@ -186,7 +186,7 @@ struct Builder {
         for (int32_t l = 1; l <= depth - 1; ++l) {
             int64_t above = total - below - cnt[l];
             double imbalance = (double)std::llabs(below - above) / (double)total;
-            double score = imbalance + 0.5 * (double)cnt[l] / (double)total * 8.0;
+            double score = imbalance + opt.sep_weight * (double)cnt[l] / (double)total;
             if (score < best_score) { best_score = score; best = l; }
             below += cnt[l];
         }
@@ -281,10 +281,17 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
             int32_t f = parent[s];
             if (f < 0) continue;
             size_t kf = b.sn_piv[f].size() - (size_t)extra_piv[f];   // original pivots of f
-            if (sn_struct[s].size() != kf + sn_struct[f].size()) continue;
             int64_t ks = (int64_t)b.sn_piv[s].size();
-            if ((int64_t)extra_piv[f] * ks > 64) continue;          // zeros between merged siblings
-            if (ks + (int64_t)b.sn_piv[f].size() > 64 && extra_piv[f] > 0) continue;
+            const bool exact = sn_struct[s].size() == kf + sn_struct[f].size();
+            // relaxed amalgamation: small fronts are merged into their parent even with explicit
+            // zeros, which collapses the chains of 1-3 pivot separators at the bottom of the tree
+            const int64_t merged_m = ks + (int64_t)b.sn_piv[f].size() + (int64_t)sn_struct[f].size();
+            const bool relaxed = opt.merge_max_m > 0 && merged_m <= opt.merge_max_m;
+            if (!exact && !relaxed) continue;
+            if (!relaxed) {
+                if ((int64_t)extra_piv[f] * ks > 64) continue;          // zeros between merged siblings
+                if (ks + (int64_t)b.sn_piv[f].size() > 64 && extra_piv[f] > 0) continue;
+            }
             // merge: child's pivots go first (they are eliminated earlier)
             std::vector<int32_t> np(b.sn_piv[s]);
             np.insert(np.end(), b.sn_piv[f].begin(), b.sn_piv[f].end());

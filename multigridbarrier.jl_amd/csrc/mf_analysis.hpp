@@ -57,6 +57,8 @@ struct MfOptions {
     int32_t leaf_size = 32;
     int32_t max_peel_rounds = 4;
     int32_t peel_max_degree = 48;
+    double sep_weight = 1.0;      // separator-size penalty in the bisection score
+    int32_t merge_max_m = 0;      // relaxed amalgamation: merge a child into its parent while m stays <= this
 };
 
 // Symmetric pattern in CSR (both triangles present, diagonal optional).  Values are not

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../include/mgbhip.h"
 #include "mf_solver.hpp"
@@ -39,6 +40,17 @@ constexpr int ST = 64;    // tile edge of the symmetric update
 // small fronts
 // ------------------------------------------------------------------------------------------------
 
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int PB = 8;     // panel width of the small-front factorization
+
+// One workgroup per front.  Right-looking LDL' blocked by PB columns: wave 0 factors the
+// m x PB panel with wave-level synchronisation only, then all waves apply the rank-PB update,
+// so a front costs 2 workgroup barriers per PB columns instead of 2 per column.
 __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                                 const int32_t* __restrict__ children, const int32_t* __restrict__ rel,
                                 const int32_t* __restrict__ a_src, const int32_t* __restrict__ a_dst,
@@ -69,84 +81,124 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
         __syncthreads();
     }
     bool bad = false;
-    for (int j = 0; j < k; ++j) {
-        const double d = W[j + j * m];
-        if (d == 0.0 || !isfinite(d)) bad = true;
-        const double inv = 1.0 / d;
-        // trailing update with the unscaled column, then scale the column: L[r,j] = W[r,j] / d
-        double* Lj = W + j * m;
-        for (int c2 = j + 1 + ty; c2 < m; c2 += TYn) {
-            const double lc = Lj[c2] * inv;
-            double* Wc = W + c2 * m;
-            for (int r = c2 + tx; r < m; r += TX) Wc[r] -= Lj[r] * lc;
+    for (int j0 = 0; j0 < k; j0 += PB) {
+        const int nb = min(PB, k - j0);
+        if (tid < 64) {
+            for (int jj = 0; jj < nb; ++jj) {
+                const int j = j0 + jj;
+                double* Lj = W + j * m;
+                const double d = Lj[j];
+                if (d == 0.0 || !isfinite(d)) bad = true;
+                const double inv = 1.0 / d;
+                for (int r = j + 1 + tid; r < m; r += 64) {
+                    const double lr = Lj[r];
+                    for (int c = j + 1; c < j0 + nb; ++c)
+                        if (r >= c) W[r + c * m] -= lr * (Lj[c] * inv);
+                }
+                wave_sync();
+                for (int r = j + 1 + tid; r < m; r += 64) Lj[r] *= inv;
+                wave_sync();
+            }
         }
         __syncthreads();
-        for (int r = j + 1 + tid; r < m; r += nt) Lj[r] *= inv;
+        const int c0 = j0 + nb;
+        for (int c = c0 + ty; c < m; c += TYn) {
+            double mult[PB];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) mult[q] = (q < nb) ? W[c + (j0 + q) * m] * W[(j0 + q) + (j0 + q) * m] : 0.0;
+            double* Wc = W + c * m;
+            for (int r = c + tx; r < m; r += TX) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < PB; ++q)
+                    if (q < nb) acc += W[r + (j0 + q) * m] * mult[q];
+                Wc[r] -= acc;
+            }
+        }
         __syncthreads();
     }
     if (bad && tid == 0) atomicOr(status, 1);
     for (int i = tid; i < mm; i += nt) Fg[i] = W[i];
 }
 
-// forward: t = L^{-1}(b + children's updates); y[piv] = D^{-1} t[0:k]; u = t[k:m]
-__global__ void mf_forward_small(const FrontDev* __restrict__ fr, int32_t first,
-                                 const int32_t* __restrict__ front_idx, const int32_t* __restrict__ children,
-                                 const int32_t* __restrict__ rel, const double* __restrict__ arena,
-                                 const double* __restrict__ b, double* __restrict__ y, double* __restrict__ uvec) {
-    extern __shared__ double t[];
-    const FrontDev F = fr[first + blockIdx.x];
+// Triangular solves of small fronts: one wave per front (4 fronts per workgroup), the work
+// vector lives in registers (rows lane and lane + 64), no workgroup barriers.
+__global__ __launch_bounds__(256) void mf_forward_small(const FrontDev* __restrict__ fr, int32_t first,
+                                                        int32_t count, int32_t ts,
+                                                        const int32_t* __restrict__ front_idx,
+                                                        const int32_t* __restrict__ children,
+                                                        const int32_t* __restrict__ rel,
+                                                        const double* __restrict__ arena,
+                                                        const double* __restrict__ b, double* __restrict__ y,
+                                                        double* __restrict__ uvec) {
+    extern __shared__ double sh[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fi = blockIdx.x * 4 + wave;
+    if (fi >= count) return;
+    const FrontDev F = fr[first + fi];
     const int m = F.m, k = F.k;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    double* t = sh + wave * ts;
     const int32_t* idx = front_idx + F.idx_off;
     const double* Fm = arena + F.F_off;
-    for (int j = tid; j < m; j += nt) t[j] = (j < k) ? b[idx[j]] : 0.0;
-    __syncthreads();
+    for (int j = lane; j < m; j += 64) t[j] = (j < k) ? b[idx[j]] : 0.0;
+    wave_sync();
     for (int c = 0; c < F.nchild; ++c) {
         const FrontDev C = fr[children[F.child_off + c]];
         const int32_t* rl = rel + C.rel_off;
         const double* uc = uvec + C.u_off;
-        for (int j = tid; j < C.m - C.k; j += nt) t[rl[j]] += uc[j];
-        __syncthreads();
+        for (int j = lane; j < C.m - C.k; j += 64) t[rl[j]] += uc[j];
+        wave_sync();
     }
+    const int r1 = lane + 64;
+    double t0 = (lane < m) ? t[lane] : 0.0;
+    double t1 = (r1 < m) ? t[r1] : 0.0;
+#pragma unroll 4
     for (int j = 0; j < k; ++j) {
-        const double tj = t[j];
         const double* Lj = Fm + (int64_t)j * m;
-        for (int r = j + 1 + tid; r < m; r += nt) t[r] -= Lj[r] * tj;
-        __syncthreads();
+        const double l0 = (lane > j && lane < m) ? Lj[lane] : 0.0;
+        const double l1 = (r1 > j && r1 < m) ? Lj[r1] : 0.0;
+        const double tj = (j < 64) ? __shfl(t0, j, 64) : __shfl(t1, j - 64, 64);
+        t0 -= l0 * tj;
+        t1 -= l1 * tj;
     }
-    for (int j = tid; j < m; j += nt) {
-        if (j < k) y[idx[j]] = t[j] / Fm[j + (int64_t)j * m];
-        else uvec[F.u_off + j - k] = t[j];
+    if (lane < m) {
+        if (lane < k) y[idx[lane]] = t0 / Fm[lane + (int64_t)lane * m];
+        else uvec[F.u_off + lane - k] = t0;
+    }
+    if (r1 < m) {
+        if (r1 < k) y[idx[r1]] = t1 / Fm[r1 + (int64_t)r1 * m];
+        else uvec[F.u_off + r1 - k] = t1;
     }
 }
 
-// backward: x[piv] = L11^{-T} (y[piv] - L21^T x[bnd])
-__global__ void mf_backward_small(const FrontDev* __restrict__ fr, int32_t first,
-                                  const int32_t* __restrict__ front_idx, const double* __restrict__ arena,
-                                  const double* __restrict__ y, double* __restrict__ x) {
-    extern __shared__ double t[];
-    __shared__ double red[256];
-    const FrontDev F = fr[first + blockIdx.x];
+__global__ __launch_bounds__(256) void mf_backward_small(const FrontDev* __restrict__ fr, int32_t first,
+                                                         int32_t count,
+                                                         const int32_t* __restrict__ front_idx,
+                                                         const double* __restrict__ arena,
+                                                         const double* __restrict__ y, double* __restrict__ x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fi = blockIdx.x * 4 + wave;
+    if (fi >= count) return;
+    const FrontDev F = fr[first + fi];
     const int m = F.m, k = F.k;
-    const int tid = threadIdx.x, nt = blockDim.x;
     const int32_t* idx = front_idx + F.idx_off;
     const double* Fm = arena + F.F_off;
-    for (int j = tid; j < m; j += nt) t[j] = (j < k) ? y[idx[j]] : x[idx[j]];
-    __syncthreads();
+    const int r1 = lane + 64;
+    double t0 = 0.0, t1 = 0.0;
+    if (lane < m) t0 = (lane < k) ? y[idx[lane]] : x[idx[lane]];
+    if (r1 < m) t1 = (r1 < k) ? y[idx[r1]] : x[idx[r1]];
+#pragma unroll 2
     for (int j = k - 1; j >= 0; --j) {
         const double* Lj = Fm + (int64_t)j * m;
         double s = 0.0;
-        for (int r = j + 1 + tid; r < m; r += nt) s += Lj[r] * t[r];
-        red[tid] = s;
-        __syncthreads();
-        for (int off = nt >> 1; off > 0; off >>= 1) {
-            if (tid < off) red[tid] += red[tid + off];
-            __syncthreads();
-        }
-        if (tid == 0) t[j] -= red[0];
-        __syncthreads();
+        if (lane > j && lane < m) s += Lj[lane] * t0;
+        if (r1 > j && r1 < m) s += Lj[r1] * t1;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == j) t0 -= s;
+        if (r1 == j) t1 -= s;
     }
-    for (int j = tid; j < k; j += nt) x[idx[j]] = t[j];
+    if (lane < k) x[idx[lane]] = t0;
+    if (r1 < k) x[idx[r1]] = t1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -205,52 +257,40 @@ __global__ __launch_bounds__(256) void mf_big_assemble(const FrontDev* __restric
     }
 }
 
-// Diagonal step: one workgroup per front factors the nb x nb diagonal block (LDL') in LDS.
-__global__ __launch_bounds__(256) void mf_big_diag(const FrontDev* __restrict__ fr, int32_t first, int j0,
-                                                   double* __restrict__ arena, int32_t* __restrict__ status) {
-    __shared__ double Dk[NB][NB + 1];
-    const FrontDev F = fr[first + blockIdx.x];
-    const int m = F.m, k = F.k;
-    if (j0 >= k) return;
-    const int nb = min(NB, k - j0);
-    double* W = arena + F.F_off;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < nb * nb; i += 256) {
-        const int r = i % nb, c = i / nb;
-        Dk[r][c] = (r >= c) ? W[(j0 + r) + (int64_t)(j0 + c) * m] : 0.0;
-    }
-    __syncthreads();
+// In-wave LDL' of an nb x nb block held in LDS (wave 0 only, wave-level synchronisation).
+__device__ __forceinline__ bool wave_ldlt(double (*Dk)[NB + 1], int nb, int lane) {
     bool bad = false;
     for (int j = 0; j < nb; ++j) {
         const double d = Dk[j][j];
         if (d == 0.0 || !isfinite(d)) bad = true;
         const double inv = 1.0 / d;
-        for (int i = tid; i < nb * nb; i += 256) {       // trailing update with the unscaled column
-            const int r = i % nb, c = i / nb;
-            if (c > j && r >= c) Dk[r][c] -= Dk[r][j] * (Dk[c][j] * inv);
+        if (lane > j && lane < nb) {
+            const double lr = Dk[lane][j];
+            for (int c = j + 1; c <= lane; ++c) Dk[lane][c] -= lr * (Dk[c][j] * inv);
         }
-        __syncthreads();
-        if (tid > j && tid < nb) Dk[tid][j] *= inv;
-        __syncthreads();
+        wave_sync();
+        if (lane > j && lane < nb) Dk[lane][j] *= inv;
+        wave_sync();
     }
-    if (bad && tid == 0) atomicOr(status, 1);
-    for (int i = tid; i < nb * nb; i += 256) {
-        const int r = i % nb, c = i / nb;
-        if (r >= c) W[(j0 + r) + (int64_t)(j0 + c) * m] = Dk[r][c];
-    }
+    return bad;
 }
 
-// Panel step: each workgroup loads the factored diagonal block and solves its TR rows of the
-// panel: L21 = A21 L11^{-T} D^{-1}.
+// Panel step.  Every workgroup of a front loads the (fully updated, still unfactored)
+// diagonal block, wave 0 factors it redundantly in LDS, then the workgroup solves its TR
+// rows of the panel: L21 = A21 L11^{-T} D^{-1}.  The factored diagonal block goes to a
+// scratch slot (`dscr`), never in place, because sibling workgroups are still reading the
+// unfactored block; the update kernel copies it home.  A front without rows below the block
+// has a single active workgroup, which writes in place.
 __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__ fr, int32_t first, int j0,
-                                                    double* __restrict__ arena) {
+                                                    double* __restrict__ arena, double* __restrict__ dscr,
+                                                    int32_t* __restrict__ status) {
     __shared__ double Dk[NB][NB + 1];
     const FrontDev F = fr[first + blockIdx.y];
     const int m = F.m, k = F.k;
     if (j0 >= k) return;
     const int nb = min(NB, k - j0);
     const int r0 = j0 + nb + blockIdx.x * TR;
-    if (r0 >= m) return;
+    if (blockIdx.x > 0 && r0 >= m) return;
     double* W = arena + F.F_off;
     const int tid = threadIdx.x;
     for (int i = tid; i < nb * nb; i += 256) {
@@ -258,12 +298,27 @@ __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__
         Dk[r][c] = (r >= c) ? W[(j0 + r) + (int64_t)(j0 + c) * m] : 0.0;
     }
     __syncthreads();
+    if (tid < 64) {
+        const bool bad = wave_ldlt(Dk, nb, tid);
+        if (bad && tid == 0 && blockIdx.x == 0) atomicOr(status, 1);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        const bool last = (j0 + nb >= m);          // no panel rows, no trailing block: write home
+        double* dst = last ? nullptr : dscr + (int64_t)blockIdx.y * (NB * NB);
+        for (int i = tid; i < nb * nb; i += 256) {
+            const int r = i % nb, c = i / nb;
+            if (r >= c) {
+                if (last) W[(j0 + r) + (int64_t)(j0 + c) * m] = Dk[r][c];
+                else dst[r + NB * c] = Dk[r][c];
+            }
+        }
+    }
     const int r = r0 + tid;
     if (r < m) {
         double a[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c) a[c] = (c < nb) ? W[r + (int64_t)(j0 + c) * m] : 0.0;
-        // y L11' = a  (unit lower L11), then l = y / d
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             if (c < nb) {
@@ -282,17 +337,18 @@ __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__
 
 // Symmetric update of the trailing block with the finished panel:
 // C[r, c] -= sum_q L[r, q] d_q L[c, q], 64 x 64 tiles of the lower triangle, 4 x 4 per thread.
+// Tile 0 also copies the factored diagonal block from the scratch slot to its home.
 __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict__ fr, int32_t first, int j0,
-                                                     double* __restrict__ arena) {
+                                                     double* __restrict__ arena, const double* __restrict__ dscr) {
     __shared__ double Pi[NB][ST + 1];
     __shared__ double Qj[NB][ST + 1];
+    __shared__ double dq[NB];
     const FrontDev F = fr[first + blockIdx.y];
     const int m = F.m, k = F.k;
     if (j0 >= k) return;
     const int nb = min(NB, k - j0);
     const int j1 = j0 + nb;
     const int T = (m - j1 + ST - 1) / ST;
-    // decode the tile pair (ti >= tj) from the linear index
     const int lin = blockIdx.x;
     int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
@@ -300,13 +356,22 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
     const int tj = lin - ti * (ti + 1) / 2;
     if (ti >= T) return;
     double* W = arena + F.F_off;
+    const double* src = dscr + (int64_t)blockIdx.y * (NB * NB);
     const int tid = threadIdx.x;
+    if (tid < nb) dq[tid] = src[tid + NB * tid];
+    if (lin == 0) {
+        for (int i = tid; i < nb * nb; i += 256) {
+            const int r = i % nb, c = i / nb;
+            if (r >= c) W[(j0 + r) + (int64_t)(j0 + c) * m] = src[r + NB * c];
+        }
+    }
+    __syncthreads();
     const int rbase = j1 + ti * ST, cbase = j1 + tj * ST;
     for (int i = tid; i < nb * ST; i += 256) {
         const int rr = i % ST, q = i / ST;
         const int r = rbase + rr, c = cbase + rr;
         Pi[q][rr] = (r < m) ? W[r + (int64_t)(j0 + q) * m] : 0.0;
-        Qj[q][rr] = (c < m) ? W[c + (int64_t)(j0 + q) * m] * W[(j0 + q) + (int64_t)(j0 + q) * m] : 0.0;
+        Qj[q][rr] = (c < m) ? W[c + (int64_t)(j0 + q) * m] * dq[q] : 0.0;
     }
     __syncthreads();
     const int tx = tid % 16, ty = tid / 16;
@@ -338,121 +403,170 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
     }
 }
 
-// Blocked forward substitution for a large front (one workgroup per front).
-__global__ __launch_bounds__(256) void mf_forward_big(const FrontDev* __restrict__ fr, int32_t first,
-                                                      const int32_t* __restrict__ front_idx,
-                                                      const int32_t* __restrict__ children,
-                                                      const int32_t* __restrict__ rel,
-                                                      const double* __restrict__ arena,
-                                                      const double* __restrict__ b, double* __restrict__ y,
-                                                      double* __restrict__ uvec, double* __restrict__ tglobal) {
-    extern __shared__ double sh[];
-    __shared__ double Dk[NB][NB + 1];
-    const FrontDev F = fr[first + blockIdx.x];
+// ---- large-front triangular solves: multi-workgroup, one launch per 32-column block step ----
+// Work vectors live in `tg` (indexed like front_idx); solved pivot blocks go to `ts` (forward)
+// or straight to x (backward), never in place, because sibling workgroups still read them.
+
+// t = [b(piv); 0] + children's update vectors; each workgroup owns 256 destination entries.
+__global__ __launch_bounds__(256) void mf_fwd_big_init(const FrontDev* __restrict__ fr, int32_t first,
+                                                       const int32_t* __restrict__ front_idx,
+                                                       const int32_t* __restrict__ children,
+                                                       const int32_t* __restrict__ rel,
+                                                       const double* __restrict__ b,
+                                                       const double* __restrict__ uvec, double* __restrict__ tg) {
+    const FrontDev F = fr[first + blockIdx.y];
     const int m = F.m, k = F.k;
+    const int d0 = blockIdx.x * 256;
+    if (d0 >= m) return;
+    const int d1 = min(d0 + 256, m);
     const int tid = threadIdx.x;
-    double* t = tglobal ? tglobal + F.idx_off : sh;
+    double* t = tg + F.idx_off;
     const int32_t* idx = front_idx + F.idx_off;
-    const double* Fm = arena + F.F_off;
-    for (int j = tid; j < m; j += 256) t[j] = (j < k) ? b[idx[j]] : 0.0;
+    const int jme = d0 + tid;
+    double v = 0.0;
+    if (jme < d1 && jme < k) v = b[idx[jme]];
+    __shared__ double tl[256];
+    tl[tid] = v;
     __syncthreads();
     for (int c = 0; c < F.nchild; ++c) {
         const FrontDev C = fr[children[F.child_off + c]];
         const int32_t* rl = rel + C.rel_off;
         const double* uc = uvec + C.u_off;
-        for (int j = tid; j < C.m - C.k; j += 256) t[rl[j]] += uc[j];
+        const int bc = C.m - C.k;
+        int lo = 0, hi = bc;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (rl[mid] < d0) lo = mid + 1; else hi = mid; }
+        const int jb = lo;
+        hi = bc;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (rl[mid] < d1) lo = mid + 1; else hi = mid; }
+        for (int j = jb + tid; j < lo; j += 256) tl[rl[j] - d0] += uc[j];
         __syncthreads();
     }
-    for (int j0 = 0; j0 < k; j0 += NB) {
-        const int nb = min(NB, k - j0);
-        for (int i = tid; i < nb * nb; i += 256) {
-            const int r = i % nb, c = i / nb;
-            Dk[r][c] = (r > c) ? Fm[(j0 + r) + (int64_t)(j0 + c) * m] : 0.0;
-        }
-        __syncthreads();
-        if (tid < 64) {                       // wave 0: unit-lower solve of the diagonal block in registers
-            double v = (tid < nb) ? t[j0 + tid] : 0.0;
-            for (int c = 0; c < nb; ++c) {
-                const double tc = __shfl(v, c, 64);
-                if (tid > c && tid < nb) v -= Dk[tid][c] * tc;
-            }
-            if (tid < nb) t[j0 + tid] = v;
-        }
-        __syncthreads();
-        for (int r = j0 + nb + tid; r < m; r += 256) {
-            double v = t[r];
-            for (int c = 0; c < nb; ++c) v -= Fm[r + (int64_t)(j0 + c) * m] * t[j0 + c];
-            t[r] = v;
-        }
-        __syncthreads();
+    if (jme < d1) t[jme] = tl[tid];
+}
+
+__global__ __launch_bounds__(256) void mf_fwd_big_step(const FrontDev* __restrict__ fr, int32_t first, int j0,
+                                                       const double* __restrict__ arena, double* __restrict__ tg,
+                                                       double* __restrict__ ts) {
+    __shared__ double Dk[NB][NB + 1];
+    __shared__ double yb[NB];
+    const FrontDev F = fr[first + blockIdx.y];
+    const int m = F.m, k = F.k;
+    if (j0 >= k) return;
+    const int nb = min(NB, k - j0);
+    const int r0 = j0 + nb + blockIdx.x * 256;
+    if (blockIdx.x > 0 && r0 >= m) return;
+    const double* Fm = arena + F.F_off;
+    double* t = tg + F.idx_off;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nb * nb; i += 256) {
+        const int r = i % nb, c = i / nb;
+        Dk[r][c] = (r > c) ? Fm[(j0 + r) + (int64_t)(j0 + c) * m] : 0.0;
     }
-    for (int j = tid; j < m; j += 256) {
-        if (j < k) y[idx[j]] = t[j] / Fm[j + (int64_t)j * m];
-        else uvec[F.u_off + j - k] = t[j];
+    __syncthreads();
+    if (tid < 64) {
+        double v = (tid < nb) ? t[j0 + tid] : 0.0;
+        for (int c = 0; c < nb; ++c) {
+            const double tc = __shfl(v, c, 64);
+            if (tid > c && tid < nb) v -= Dk[tid][c] * tc;
+        }
+        if (tid < nb) {
+            yb[tid] = v;
+            if (blockIdx.x == 0) ts[F.idx_off + j0 + tid] = v;
+        }
+    }
+    __syncthreads();
+    const int r = r0 + tid;
+    if (r < m) {
+        double v = t[r];
+        for (int c = 0; c < nb; ++c) v -= Fm[r + (int64_t)(j0 + c) * m] * yb[c];
+        t[r] = v;
     }
 }
 
-// Blocked backward substitution for a large front.
-__global__ __launch_bounds__(256) void mf_backward_big(const FrontDev* __restrict__ fr, int32_t first,
+__global__ __launch_bounds__(256) void mf_fwd_big_fin(const FrontDev* __restrict__ fr, int32_t first,
+                                                      const int32_t* __restrict__ front_idx,
+                                                      const double* __restrict__ arena,
+                                                      const double* __restrict__ tg, const double* __restrict__ ts,
+                                                      double* __restrict__ y, double* __restrict__ uvec) {
+    const FrontDev F = fr[first + blockIdx.y];
+    const int m = F.m, k = F.k;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const double* Fm = arena + F.F_off;
+    if (j < k) y[front_idx[F.idx_off + j]] = ts[F.idx_off + j] / Fm[j + (int64_t)j * m];
+    else uvec[F.u_off + j - k] = tg[F.idx_off + j];
+}
+
+// v[q] = y[piv q] - sum_{r >= k} L[r, q] x[bnd r]: one wave per pivot column.
+__global__ __launch_bounds__(256) void mf_bwd_big_init(const FrontDev* __restrict__ fr, int32_t first,
                                                        const int32_t* __restrict__ front_idx,
                                                        const double* __restrict__ arena,
-                                                       const double* __restrict__ y, double* __restrict__ x,
-                                                       double* __restrict__ tglobal) {
-    extern __shared__ double sh[];
-    __shared__ double Dk[NB][NB + 1];
-    __shared__ double part[4][NB];
-    const FrontDev F = fr[first + blockIdx.x];
+                                                       const double* __restrict__ y, const double* __restrict__ x,
+                                                       double* __restrict__ tg) {
+    const FrontDev F = fr[first + blockIdx.y];
     const int m = F.m, k = F.k;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    double* t = tglobal ? tglobal + F.idx_off : sh;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= k) return;
     const int32_t* idx = front_idx + F.idx_off;
+    const double* Lq = arena + F.F_off + (int64_t)q * m;
+    double s = 0.0;
+    for (int r = k + lane; r < m; r += 64) s += Lq[r] * x[idx[r]];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) tg[F.idx_off + q] = y[idx[q]] - s;
+}
+
+// Block step (descending j0): solve the unit-upper diagonal block, publish x, and update the
+// entries q < j0 with rows j0..j0+nb of L (32 contiguous doubles per column).
+__global__ __launch_bounds__(256) void mf_bwd_big_step(const FrontDev* __restrict__ fr, int32_t first, int j0,
+                                                       const int32_t* __restrict__ front_idx,
+                                                       const double* __restrict__ arena, double* __restrict__ tg,
+                                                       double* __restrict__ x) {
+    __shared__ double Dk[NB][NB + 1];
+    __shared__ double xb[NB];
+    const FrontDev F = fr[first + blockIdx.y];
+    const int m = F.m, k = F.k;
+    if (j0 >= k) return;
+    const int nb = min(NB, k - j0);
+    const int q0 = blockIdx.x * 256;
+    if (blockIdx.x > 0 && q0 >= j0) return;
     const double* Fm = arena + F.F_off;
-    for (int j = tid; j < m; j += 256) t[j] = (j < k) ? y[idx[j]] : x[idx[j]];
-    __syncthreads();
-    const int nblk = (k + NB - 1) / NB;
-    for (int bi = nblk - 1; bi >= 0; --bi) {
-        const int j0 = bi * NB;
-        const int nb = min(NB, k - j0);
-        // acc[c] = sum_{r >= j0+nb} L[r, j0+c] t[r]
-        double acc[NB];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) acc[c] = 0.0;
-        for (int r = j0 + nb + tid; r < m; r += 256) {
-            const double tr = t[r];
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-                if (c < nb) acc[c] += Fm[r + (int64_t)(j0 + c) * m] * tr;
-        }
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            double v = acc[c];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) part[wave][c] = v;
-        }
-        for (int i = tid; i < nb * nb; i += 256) {
-            const int r = i % nb, c = i / nb;
-            Dk[r][c] = (r > c) ? Fm[(j0 + r) + (int64_t)(j0 + c) * m] : 0.0;
-        }
-        __syncthreads();
-        if (tid < 64) {                       // wave 0: unit-upper (L11') solve in registers
-            double v = 0.0;
-            if (tid < nb) v = t[j0 + tid] - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
-            for (int c = nb - 1; c >= 0; --c) {
-                const double xc = __shfl(v, c, 64);
-                if (tid < c) v -= Dk[c][tid] * xc;
-            }
-            if (tid < nb) t[j0 + tid] = v;
-        }
-        __syncthreads();
+    double* t = tg + F.idx_off;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nb * nb; i += 256) {
+        const int r = i % nb, c = i / nb;
+        Dk[r][c] = (r > c) ? Fm[(j0 + r) + (int64_t)(j0 + c) * m] : 0.0;
     }
-    for (int j = tid; j < k; j += 256) x[idx[j]] = t[j];
+    __syncthreads();
+    if (tid < 64) {
+        double v = (tid < nb) ? t[j0 + tid] : 0.0;
+        for (int c = nb - 1; c >= 0; --c) {
+            const double xc = __shfl(v, c, 64);
+            if (tid < c) v -= Dk[c][tid] * xc;
+        }
+        if (tid < nb) {
+            xb[tid] = v;
+            if (blockIdx.x == 0) x[front_idx[F.idx_off + j0 + tid]] = v;
+        }
+    }
+    __syncthreads();
+    const int q = q0 + tid;
+    if (q < j0) {
+        const double* Lq = Fm + (int64_t)q * m + j0;
+        double v = t[q];
+        for (int c = 0; c < nb; ++c) v -= Lq[c] * xb[c];
+        t[q] = v;
+    }
 }
 
 }  // namespace
 
 void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st) {
     MfOptions opt;
+    // tuning overrides (defaults are the measured best on MI355X)
+    if (const char* e = getenv("MGBHIP_LEAF")) opt.leaf_size = atoi(e);
+    if (const char* e = getenv("MGBHIP_SEPW")) opt.sep_weight = atof(e);
+    if (const char* e = getenv("MGBHIP_MERGE")) opt.merge_max_m = atoi(e);
     mf_analyze(n, rowptr, colidx, opt, plan);
     const int32_t nf = (int32_t)plan.fronts.size();
     std::vector<FrontDev> fd(nf);
@@ -470,6 +584,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     d_uvec.alloc((size_t)std::max<int64_t>(plan.uvec_doubles, 1));
     d_y.alloc((size_t)std::max<int64_t>(plan.n, 1));
     d_tbig.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
+    d_tsol.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
     d_status.alloc(1);
     d_status.zero(st);
 
@@ -480,9 +595,6 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
         lds_cap = 128;
     else
         (void)hipGetLastError();
-    (void)hipFuncSetAttribute((const void*)mf_forward_big, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)mf_backward_big, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipGetLastError();
 
     static const int32_t classes[] = {16, 32, 48, 64, 88, 128};
     level_launches.clear();
@@ -513,6 +625,11 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             i = j;
         }
     }
+    int32_t max_big = 1;
+    for (auto& lev : level_launches)
+        for (auto& L : lev)
+            if (!L.cls) max_big = std::max(max_big, L.count);
+    d_dscr.alloc((size_t)max_big * NB * NB);
     analyzed = true;
     MGB_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
 }
@@ -536,15 +653,15 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,
                                    d_a_src.p, d_a_dst.p, d_values, d_arena.p);
                 for (int j0 = 0; j0 < L.max_k; j0 += NB) {
-                    const int rem = L.max_m - j0;                // rows below the panel start, at most
-                    const dim3 gp(std::max(1, (rem + TR - 1) / TR), L.count);
-                    hipLaunchKernelGGL(mf_big_diag, dim3(L.count), dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p,
-                                       d_status.p);
-                    hipLaunchKernelGGL(mf_big_panel, gp, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p);
+                    const int rem = L.max_m - j0;                // rows from the panel start, at most
+                    const dim3 gp(std::max(1, (rem - 1 + TR - 1) / TR), L.count);
+                    hipLaunchKernelGGL(mf_big_panel, gp, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p,
+                                       d_dscr.p, d_status.p);
                     const int T = (rem - 1 + ST - 1) / ST;       // trailing tiles (upper bound)
                     if (T > 0) {
                         const dim3 gu(T * (T + 1) / 2, L.count);
-                        hipLaunchKernelGGL(mf_big_update, gu, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p);
+                        hipLaunchKernelGGL(mf_big_update, gu, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p,
+                                           d_dscr.p);
                     }
                 }
             }
@@ -556,19 +673,26 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
 void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers* timers) {
     MGB_REQUIRE(analyzed, "MfSolver::solve before analyze");
     if (timers) timers->begin("trisolve");
-    const size_t LDS_T_CAP = 15000;   // doubles of work vector kept in LDS by the large-front solves
     for (auto& lev : level_launches)
         for (auto& L : lev) {
             if (L.count == 0) continue;
             if (L.cls) {
-                hipLaunchKernelGGL(mf_forward_small, dim3(L.count), dim3(small_threads(L.cls)),
-                                   (size_t)L.max_m * sizeof(double), st, d_fronts.p, L.first, d_front_idx.p,
-                                   d_children.p, d_rel.p, d_arena.p, d_b, d_y.p, d_uvec.p);
+                const int ts = (L.max_m + 1) & ~1;
+                hipLaunchKernelGGL(mf_forward_small, dim3((L.count + 3) / 4), dim3(256), (size_t)4 * ts * sizeof(double),
+                                   st, d_fronts.p, L.first, L.count, ts, d_front_idx.p, d_children.p, d_rel.p,
+                                   d_arena.p, d_b, d_y.p, d_uvec.p);
             } else {
-                const bool glob = (size_t)L.max_m > LDS_T_CAP;
-                hipLaunchKernelGGL(mf_forward_big, dim3(L.count), dim3(256), glob ? 0 : (size_t)L.max_m * sizeof(double),
-                                   st, d_fronts.p, L.first, d_front_idx.p, d_children.p, d_rel.p, d_arena.p, d_b,
-                                   d_y.p, d_uvec.p, glob ? d_tbig.p : (double*)nullptr);
+                const dim3 gi((L.max_m + 255) / 256, L.count);
+                hipLaunchKernelGGL(mf_fwd_big_init, gi, dim3(256), 0, st, d_fronts.p, L.first, d_front_idx.p,
+                                   d_children.p, d_rel.p, d_b, d_uvec.p, d_tbig.p);
+                for (int j0 = 0; j0 < L.max_k; j0 += NB) {
+                    const int rem = L.max_m - j0;
+                    const dim3 gs(std::max(1, (rem - 1 + 255) / 256), L.count);
+                    hipLaunchKernelGGL(mf_fwd_big_step, gs, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p,
+                                       d_tbig.p, d_tsol.p);
+                }
+                hipLaunchKernelGGL(mf_fwd_big_fin, gi, dim3(256), 0, st, d_fronts.p, L.first, d_front_idx.p,
+                                   d_arena.p, d_tbig.p, d_tsol.p, d_y.p, d_uvec.p);
             }
         }
     for (int32_t l = (int32_t)level_launches.size() - 1; l >= 0; --l)
@@ -576,14 +700,18 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
             const MfLaunch& L = *it;
             if (L.count == 0) continue;
             if (L.cls) {
-                hipLaunchKernelGGL(mf_backward_small, dim3(L.count), dim3(small_threads(L.cls)),
-                                   (size_t)L.max_m * sizeof(double), st, d_fronts.p, L.first, d_front_idx.p,
-                                   d_arena.p, d_y.p, d_x);
+                hipLaunchKernelGGL(mf_backward_small, dim3((L.count + 3) / 4), dim3(256), 0, st, d_fronts.p, L.first,
+                                   L.count, d_front_idx.p, d_arena.p, d_y.p, d_x);
             } else {
-                const bool glob = (size_t)L.max_m > LDS_T_CAP;
-                hipLaunchKernelGGL(mf_backward_big, dim3(L.count), dim3(256),
-                                   glob ? 0 : (size_t)L.max_m * sizeof(double), st, d_fronts.p, L.first,
-                                   d_front_idx.p, d_arena.p, d_y.p, d_x, glob ? d_tbig.p : (double*)nullptr);
+                const dim3 gi((L.max_k + 3) / 4, L.count);
+                hipLaunchKernelGGL(mf_bwd_big_init, gi, dim3(256), 0, st, d_fronts.p, L.first, d_front_idx.p,
+                                   d_arena.p, d_y.p, d_x, d_tbig.p);
+                const int last = ((L.max_k - 1) / NB) * NB;
+                for (int j0 = last; j0 >= 0; j0 -= NB) {
+                    const dim3 gs(std::max(1, (j0 + 255) / 256), L.count);
+                    hipLaunchKernelGGL(mf_bwd_big_step, gs, dim3(256), 0, st, d_fronts.p, L.first, j0, d_front_idx.p,
+                                       d_arena.p, d_tbig.p, d_x);
+                }
             }
         }
     MGB_HIP_CHECK(hipGetLastError());

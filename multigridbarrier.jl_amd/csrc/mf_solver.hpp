@@ -36,8 +36,7 @@ class MfSolver {
    private:
     DevBuf<FrontDev> d_fronts;
     DevBuf<int32_t> d_front_idx, d_children, d_rel, d_a_src, d_a_dst;
-    DevBuf<double> d_arena, d_uvec, d_y, d_tbig;
-    bool d_tbig_ready = false;
+    DevBuf<double> d_arena, d_uvec, d_y, d_tbig, d_tsol, d_dscr;
     DevBuf<int32_t> d_status;
     std::vector<std::vector<MfLaunch>> level_launches;   // per level, leaves first
     int32_t lds_cap = 88;           // largest m factored out of LDS

@@ -7,6 +7,7 @@
 // `solve(symmetric(H), g)` (src/utils.jl:142-145) -- SuperLU alone would understate the
 // reference's CPU path by an order of magnitude.
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -119,6 +120,8 @@ extern "C" void* mf_host_analyze(int64_t n, const int32_t* rowptr, const int32_t
     auto* S = new HostSolver();
     MfOptions opt;
     if (leaf_size > 0) opt.leaf_size = leaf_size;
+    if (const char* e = getenv("MF_SEPW")) opt.sep_weight = atof(e);
+    if (const char* e = getenv("MF_MERGE")) opt.merge_max_m = atoi(e);
     try {
         mf_analyze(n, rowptr, colidx, opt, S->plan);
     } catch (const std::exception&) {
@@ -210,4 +213,15 @@ extern "C" int mf_host_factor_solve(void* h, const double* values, const double*
         for (int32_t j = 0; j < k; ++j) x[idx[j]] = t[j];
     }
     return status;
+}
+
+// plan inspection for tests / tuning: per front (level, m, k, nchild)
+extern "C" int64_t mf_host_plan_fronts(void* h, int32_t* out4, int64_t cap) {
+    HostSolver* S = (HostSolver*)h;
+    const int64_t nf = (int64_t)S->plan.fronts.size();
+    for (int64_t i = 0; i < nf && i < cap; ++i) {
+        const Front& f = S->plan.fronts[i];
+        out4[4 * i + 0] = f.level; out4[4 * i + 1] = f.m; out4[4 * i + 2] = f.k; out4[4 * i + 3] = f.nchild;
+    }
+    return nf;
 }
