@@ -367,14 +367,33 @@ __global__ __launch_bounds__(256) void gather_assemble_kernel(int64_t nnz, const
     Hval[q] = s;
 }
 
-// General (coarse) levels: one workgroup per element; thread (ia, ib) computes
-// panel_a[:, ia]' * Hel_ab * panel_b[:, ib] into the element's projected slab (deterministic;
-// the structural nonzeros of H gather from the slab afterwards).
+// Long contribution lists (coarse levels: few unknowns, every element contributes): one wave per
+// structural nonzero, lanes stride over the list, fixed-order shuffle reduction.
+__global__ __launch_bounds__(256) void gather_assemble_wave_kernel(int64_t nnz, const int32_t* __restrict__ cptr,
+                                                                   const int32_t* __restrict__ cidx,
+                                                                   const double* __restrict__ slab,
+                                                                   double* __restrict__ Hval) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nnz) return;
+    double s = 0.0;
+    for (int32_t t = cptr[q] + lane; t < cptr[q + 1]; t += 64) s += slab[cidx[t]];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) Hval[q] = s;
+}
+
+// General (coarse) levels: one wave per element computes the projected block
+// [panel_0 .. panel_{nu-1}]' * Hel_e * [panel_0 .. panel_{nu-1}] in two steps per block pair
+// (tmp = Hel_ab * panel_b in LDS, then panel_a' * tmp) into the element's slab; the structural
+// nonzeros of H gather from the slab afterwards (deterministic, no atomics).
 __global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P) {
-    const int64_t e = blockIdx.x;
+    extern __shared__ double sh[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+    if (e >= P.N) return;
     const int p = P.p, nu = P.nu;
-    const int NB = nu * (nu + 1) / 2;
-    const int tid = threadIdx.x;
+    const int NB2 = nu * (nu + 1) / 2;
+    double* tmp = sh + (size_t)wave * p * P.cmax;
     const int32_t base = P.ecol_ptr[e * nu];
     const int32_t ct = P.ecol_ptr[(e + 1) * nu] - base;
     double* out = P.slab + P.eoff[e];
@@ -386,22 +405,25 @@ __global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P)
             const double* pb = P.panels + (int64_t)p * ob;
             const bool tr = a > b;
             const int blk = tr ? (b * nu - (b * (b - 1)) / 2 + (a - b)) : (a * nu - (a * (a - 1)) / 2 + (b - a));
-            const double* Hb = P.hel + (e * NB + blk) * (int64_t)p * p;
-            for (int t = tid; t < ca * cb; t += 256) {
+            const double* Hb = P.hel + (e * NB2 + blk) * (int64_t)p * p;
+            for (int t = lane; t < p * cb; t += 64) {
+                const int rr = t % p, ib = t / p;
+                double acc = 0.0;
+                for (int ss = 0; ss < p; ++ss) acc += (tr ? Hb[ss + p * rr] : Hb[rr + p * ss]) * pb[ss + p * ib];
+                tmp[t] = acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int t = lane; t < ca * cb; t += 64) {
                 const int ia = t % ca, ib = t / ca;
                 double acc = 0.0;
-                for (int ss = 0; ss < p; ++ss) {
-                    const double pbv = pb[ss + p * ib];
-                    if (pbv == 0.0) continue;
-                    double inner = 0.0;
-                    for (int rr = 0; rr < p; ++rr) {
-                        const double h = tr ? Hb[ss + p * rr] : Hb[rr + p * ss];
-                        inner += pa[rr + p * ia] * h;
-                    }
-                    acc += inner * pbv;
-                }
+                for (int rr = 0; rr < p; ++rr) acc += pa[rr + p * ia] * tmp[rr + p * ib];
                 out[(oa - base + ia) + (int64_t)ct * (ob - base + ib)] = acc;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
@@ -542,16 +564,22 @@ void launch_axpy(double alpha, const double* x, double* y, int64_t len, hipStrea
 }
 
 void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,
-                            double* Hval, hipStream_t st) {
+                            double* Hval, bool long_lists, hipStream_t st) {
     if (nnz == 0) return;
-    hipLaunchKernelGGL(gather_assemble_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, cptr, cidx,
-                       slab, Hval);
+    if (long_lists)
+        hipLaunchKernelGGL(gather_assemble_wave_kernel, dim3((unsigned)((nnz + 3) / 4)), dim3(256), 0, st, nnz, cptr,
+                           cidx, slab, Hval);
+    else
+        hipLaunchKernelGGL(gather_assemble_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, cptr,
+                           cidx, slab, Hval);
     MGB_HIP_CHECK(hipGetLastError());
 }
 
 void launch_panel_project(const PanelParams& P, hipStream_t st) {
     if (P.N == 0) return;
-    hipLaunchKernelGGL(panel_project_kernel, dim3((unsigned)P.N), dim3(256), 0, st, P);
+    const size_t lds = (size_t)4 * P.p * P.cmax * sizeof(double);
+    MGB_REQUIRE(lds <= 64 * 1024, "coarse-level panels too wide for the projection kernel");
+    hipLaunchKernelGGL(panel_project_kernel, dim3((unsigned)((P.N + 3) / 4)), dim3(256), lds, st, P);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

@@ -60,7 +60,7 @@ void launch_axpy(double alpha, const double* x, double* y, int64_t len, hipStrea
 
 // selection levels: H[q] = sum_{t in contributions(q)} slab[cidx[t]]
 void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,
-                            double* Hval, hipStream_t st);
+                            double* Hval, bool long_lists, hipStream_t st);
 
 // general (coarse) levels: slab_e = [panel_0 .. panel_{nu-1}]' * Hel_e * [panel_0 .. panel_{nu-1}]
 // (c_tot x c_tot, column-major, at eoff[e]); the structural nonzeros then gather from the slab.
@@ -72,6 +72,7 @@ struct PanelParams {
     const int32_t* eoff;          // [N + 1] slab offsets
     const double* hel;
     double* slab;
+    int32_t cmax;                 // largest per-(element, state) column count
 };
 void launch_panel_project(const PanelParams& P, hipStream_t st);
 

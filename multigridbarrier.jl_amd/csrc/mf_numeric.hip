@@ -46,11 +46,32 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int PB = 8;     // panel width of the small-front factorization
+// In-register LDL' of an nb x nb block: lane r holds row r of the lower triangle in a[0..r].
+// 32 x 31 / 2 shuffle + FMA pairs, no memory traffic; nb is wave-uniform.
+__device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NB], int nb, int lane) {
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (j < nb) {
+            const double d = __shfl(a[j], j, 64);
+            if (d == 0.0 || !isfinite(d)) bad = true;
+            const double inv = 1.0 / d;
+            const double aj = a[j];          // this lane's unscaled entry of column j
+            const double lr = aj * inv;
+#pragma unroll
+            for (int c = j + 1; c < NB; ++c) {
+                const double v = __shfl(aj, c, 64);      // unscaled entry (c, j)
+                if (c < nb && lane >= c) a[c] -= lr * v;
+            }
+            if (lane > j) a[j] = lr;
+        }
+    }
+    return bad;
+}
 
-// One workgroup per front.  Right-looking LDL' blocked by PB columns: wave 0 factors the
-// m x PB panel with wave-level synchronisation only, then all waves apply the rank-PB update,
-// so a front costs 2 workgroup barriers per PB columns instead of 2 per column.
+// One workgroup per front.  Right-looking LDL' blocked by NB = 32 columns: wave 0 factors the
+// diagonal block in registers (shuffles only), every thread then solves one panel row in
+// registers, and all threads apply the rank-32 update -- 3 workgroup barriers per 32 columns.
 __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                                 const int32_t* __restrict__ children, const int32_t* __restrict__ rel,
                                 const int32_t* __restrict__ a_src, const int32_t* __restrict__ a_dst,
@@ -81,36 +102,50 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
         __syncthreads();
     }
     bool bad = false;
-    for (int j0 = 0; j0 < k; j0 += PB) {
-        const int nb = min(PB, k - j0);
-        if (tid < 64) {
-            for (int jj = 0; jj < nb; ++jj) {
-                const int j = j0 + jj;
-                double* Lj = W + j * m;
-                const double d = Lj[j];
-                if (d == 0.0 || !isfinite(d)) bad = true;
-                const double inv = 1.0 / d;
-                for (int r = j + 1 + tid; r < m; r += 64) {
-                    const double lr = Lj[r];
-                    for (int c = j + 1; c < j0 + nb; ++c)
-                        if (r >= c) W[r + c * m] -= lr * (Lj[c] * inv);
+    for (int j0 = 0; j0 < k; j0 += NB) {
+        const int nb = min(NB, k - j0);
+        if (tid < 64) {                       // diagonal block in registers
+            double a[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) a[c] = (tid < nb && c <= tid) ? W[(j0 + tid) + (j0 + c) * m] : 0.0;
+            bad |= wave_ldlt_regs(a, nb, tid);
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (tid < nb && c <= tid) W[(j0 + tid) + (j0 + c) * m] = a[c];
+        }
+        __syncthreads();
+        {                                     // panel rows: l = (a L11^{-T}) D^{-1}, one row per thread
+            const int r = j0 + nb + tid;
+            if (r < m) {
+                double a[NB];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) a[c] = (c < nb) ? W[r + (j0 + c) * m] : 0.0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    if (c < nb) {
+                        double v = a[c];
+#pragma unroll
+                        for (int q = 0; q < NB; ++q)
+                            if (q < c) v -= a[q] * W[(j0 + c) + (j0 + q) * m];
+                        a[c] = v;
+                    }
                 }
-                wave_sync();
-                for (int r = j + 1 + tid; r < m; r += 64) Lj[r] *= inv;
-                wave_sync();
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    if (c < nb) W[r + (j0 + c) * m] = a[c] / W[(j0 + c) + (j0 + c) * m];
             }
         }
         __syncthreads();
         const int c0 = j0 + nb;
         for (int c = c0 + ty; c < m; c += TYn) {
-            double mult[PB];
+            double mult[NB];
 #pragma unroll
-            for (int q = 0; q < PB; ++q) mult[q] = (q < nb) ? W[c + (j0 + q) * m] * W[(j0 + q) + (j0 + q) * m] : 0.0;
+            for (int q = 0; q < NB; ++q) mult[q] = (q < nb) ? W[c + (j0 + q) * m] * W[(j0 + q) + (j0 + q) * m] : 0.0;
             double* Wc = W + c * m;
             for (int r = c + tx; r < m; r += TX) {
                 double acc = 0.0;
 #pragma unroll
-                for (int q = 0; q < PB; ++q)
+                for (int q = 0; q < NB; ++q)
                     if (q < nb) acc += W[r + (j0 + q) * m] * mult[q];
                 Wc[r] -= acc;
             }
@@ -257,24 +292,6 @@ __global__ __launch_bounds__(256) void mf_big_assemble(const FrontDev* __restric
     }
 }
 
-// In-wave LDL' of an nb x nb block held in LDS (wave 0 only, wave-level synchronisation).
-__device__ __forceinline__ bool wave_ldlt(double (*Dk)[NB + 1], int nb, int lane) {
-    bool bad = false;
-    for (int j = 0; j < nb; ++j) {
-        const double d = Dk[j][j];
-        if (d == 0.0 || !isfinite(d)) bad = true;
-        const double inv = 1.0 / d;
-        if (lane > j && lane < nb) {
-            const double lr = Dk[lane][j];
-            for (int c = j + 1; c <= lane; ++c) Dk[lane][c] -= lr * (Dk[c][j] * inv);
-        }
-        wave_sync();
-        if (lane > j && lane < nb) Dk[lane][j] *= inv;
-        wave_sync();
-    }
-    return bad;
-}
-
 // Panel step.  Every workgroup of a front loads the (fully updated, still unfactored)
 // diagonal block, wave 0 factors it redundantly in LDS, then the workgroup solves its TR
 // rows of the panel: L21 = A21 L11^{-T} D^{-1}.  The factored diagonal block goes to a
@@ -299,7 +316,13 @@ __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__
     }
     __syncthreads();
     if (tid < 64) {
-        const bool bad = wave_ldlt(Dk, nb, tid);
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = (tid < nb && c <= tid) ? Dk[tid][c] : 0.0;
+        const bool bad = wave_ldlt_regs(a, nb, tid);
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            if (tid < nb && c <= tid) Dk[tid][c] = a[c];
         if (bad && tid == 0 && blockIdx.x == 0) atomicOr(status, 1);
     }
     __syncthreads();

@@ -312,6 +312,7 @@ void mgbhip_problem::ensure_plan(int level) {
             MGB_REQUIRE(total < (int64_t)INT32_MAX, "contribution list exceeds 32-bit indexing");
             ccount[q + 1] += ccount[q];
         }
+        L.long_lists = L.nnz > 0 && total / L.nnz > 48;
         std::vector<int32_t> fill(ccount.begin(), ccount.end() - 1);
         std::vector<int32_t> cidx((size_t)total);
         for_each([&](int32_t pos, int64_t src) {
@@ -338,6 +339,8 @@ void mgbhip_problem::ensure_plan(int level) {
                     }
                 }
             }
+        L.cmax = 1;
+        for (size_t q = 0; q + 1 < ecol_ptr.size(); ++q) L.cmax = std::max(L.cmax, ecol_ptr[q + 1] - ecol_ptr[q]);
         std::vector<int32_t> eoff32(eoff.begin(), eoff.end());
         L.eoff.upload(eoff32, st);
         L.ecol_ptr.upload(ecol_ptr, st);
@@ -423,14 +426,14 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
     {
         StageScope sc(ctx->timers, "assemble");
         if (L.selection) {
-            launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, d_hel.p, L.Hval.p, st);
+            launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, d_hel.p, L.Hval.p, L.long_lists, st);
         } else {
             PanelParams PP;
             PP.p = p; PP.nu = nu; PP.N = N;
             PP.ecol_ptr = L.ecol_ptr.p; PP.panels = L.panels.p; PP.eoff = L.eoff.p;
-            PP.hel = d_hel.p; PP.slab = L.slab.p;
+            PP.hel = d_hel.p; PP.slab = L.slab.p; PP.cmax = L.cmax;
             launch_panel_project(PP, st);
-            launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, st);
+            launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st);
         }
     }
     L.have_H = true;

@@ -40,6 +40,8 @@ struct Level {
     DevBuf<int32_t> Hptr, Hcol, cptr, cidx, ecol_ptr, ecols, eoff;
     DevBuf<double> Hval, panels, slab;
     int64_t slab_doubles = 0;
+    int32_t cmax = 1;
+    bool long_lists = false;
     int64_t nnz = 0;
     MfSolver solver;
     bool have_H = false, factored = false;
