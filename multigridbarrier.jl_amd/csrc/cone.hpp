@@ -275,10 +275,95 @@ __device__ __forceinline__ void piece_accumulate(const PieceDev& P, int64_t node
     }
 }
 
+// Fast path of the most common Convex: a single Euclidean-power piece with A = I, b = 0, no
+// select grid (the reference's default p-Laplace cone, src/mgb.jl:722).  Same formulas as
+// core_grad / core_hess (src/convex_euclidian_power.jl:387-433) with the four powers of s
+// derived from one exp/log pair: s^(a-1) = s^a / s, s^(a-2) = s^a / s^2, s^(2a-2) = (s^a / s)^2.
+template <int NY, int ORDER>
+__device__ __forceinline__ void ep_identity_eval(const PieceDev& P, int64_t node, const double (&y)[NY],
+                                                 double& F, double (&g)[NY], double (&H)[NY * NY]) {
+    constexpr int MI = MGBHIP_MAX_IDX;
+    const int nz = P.ni;
+    double z[MI];
+#pragma unroll
+    for (int c = 0; c < MI; ++c) z[c] = (c < nz) ? pick<NY>(y, P.idx[c]) : 0.0;
+    const double p0 = P.p ? P.p[node] : P.p_const;
+    const double mu = P.mu ? P.mu[node] : P.mu_const;
+    double qsq = 0.0;
+#pragma unroll
+    for (int c = 0; c < MI; ++c) qsq += (c < nz - 1) ? z[c] * z[c] : 0.0;
+    const double s = pick<MI>(z, nz - 1);
+    const double alpha = 2.0 / p0;
+    const double ls = mgb_Log(s);
+    const double s_a = exp(alpha * ls);
+    const double rr = s_a - qsq;
+    if (ORDER == 0) {
+        F = -mgb_Log(rr) - mu * ls;
+        return;
+    }
+    const double inv_r = 1.0 / rr;
+    const double inv_s = 1.0 / s;
+    const double s_am1 = s_a * inv_s;
+    double gz[MI], Hz[MI * MI];
+    if (ORDER == 1) {
+#pragma unroll
+        for (int c = 0; c < MI; ++c)
+            gz[c] = (c < nz - 1) ? 2.0 * inv_r * z[c] : ((c == nz - 1) ? (-alpha * s_am1 * inv_r - mu * inv_s) : 0.0);
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            double add = 0.0;
+#pragma unroll
+            for (int c = 0; c < MI; ++c) add = (c < nz && P.idx[c] == i) ? gz[c] : add;
+            g[i] = add;
+        }
+        return;
+    }
+    const double inv_r2 = inv_r * inv_r;
+    const double coef_qs = -2.0 * alpha * s_am1 * inv_r2;
+    const double s_am2 = s_am1 * inv_s;
+    const double H_ss = -alpha * (alpha - 1.0) * s_am2 * inv_r + alpha * alpha * (s_am1 * s_am1) * inv_r2 + mu * inv_s * inv_s;
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            double v = 0.0;
+            const bool iq = i < nz - 1, jq = j < nz - 1;
+            const bool is = i == nz - 1, js = j == nz - 1;
+            if (iq && jq) v = 4.0 * z[i] * z[j] * inv_r2 + (i == j ? 2.0 * inv_r : 0.0);
+            else if (iq && js) v = coef_qs * z[i];
+            else if (is && jq) v = coef_qs * z[j];
+            else if (is && js) v = H_ss;
+            Hz[i + MI * j] = v;
+        }
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+        int ki = -1;
+#pragma unroll
+        for (int c = 0; c < MI; ++c) ki = (c < nz && P.idx[c] == i) ? c : ki;
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+            int kj = -1;
+#pragma unroll
+            for (int c = 0; c < MI; ++c) kj = (c < nz && P.idx[c] == j) ? c : kj;
+            double v = 0.0;
+            if (ki >= 0 && kj >= 0) {
+#pragma unroll
+                for (int q = 0; q < MI * MI; ++q) v = (q == ki + MI * kj) ? Hz[q] : v;
+            }
+            H[i * NY + j] = v;
+        }
+    }
+}
+
 // Full node barrier: value F, gradient g, Hessian H for the Convex or its phase-I wrapper.
 template <int NY, int ORDER>
 __device__ __forceinline__ void cone_eval(const ConeDev& C, int64_t node, int64_t n, const double (&y)[NY],
                                           double& F, double (&g)[NY], double (&H)[NY * NY]) {
+    if (C.npieces == 1 && !C.feasibility && C.pc[0].kind == MGBHIP_KIND_EP && C.pc[0].A == nullptr &&
+        C.pc[0].b == nullptr && C.pc[0].select == nullptr) {
+        ep_identity_eval<NY, ORDER>(C.pc[0], node, y, F, g, H);
+        return;
+    }
     F = 0.0;
     if (ORDER == 1) {
 #pragma unroll

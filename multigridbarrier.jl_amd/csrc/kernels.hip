@@ -12,6 +12,7 @@
 // section 8(d): operators + z + grids in, element blocks out.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "kernels.hpp"
@@ -57,14 +58,7 @@ __global__ __launch_bounds__(256) void elem_kernel(const ElemParams P, const int
     }
     // 2. fine broken-basis values of this element: z0 + R*s  (src/convex.jl:156)
     if (active) {
-        for (int a = 0; a < nu; ++a) {
-            const int64_t row = (int64_t)a * n + node;
-            double v = P.z0[row];
-            if (P.s != nullptr) {
-                for (int32_t q = P.Rptr[row]; q < P.Rptr[row + 1]; ++q) v += P.Rval[q] * P.s[P.Rcol[q]];
-            }
-            zl[(el * nu + a) * G + r] = v;
-        }
+        for (int a = 0; a < nu; ++a) zl[(el * nu + a) * G + r] = P.z0[(int64_t)a * n + node];
     }
     __syncthreads();
 
@@ -192,7 +186,7 @@ __global__ __launch_bounds__(256) void elem_kernel(const ElemParams P, const int
             for (int a = 0; a < nu; ++a)
                 for (int b = a; b < nu; ++b) {
                     const int blk = a * nu - (a * (a - 1)) / 2 + (b - a);
-                    double* out = P.out_hel + ((e * NB + blk) * p + j) * (int64_t)p;
+                    double* out = P.out_hel + (((int64_t)blk * P.N + e) * p + j) * (int64_t)p;
                     for (int i = 0; i < p; ++i) {
                         double val = 0.0;
 #pragma unroll
@@ -224,6 +218,180 @@ __global__ __launch_bounds__(256) void elem_kernel(const ElemParams P, const int
         }
         return;
     }
+}
+
+// Specialised element Hessian kernel for compile-time (NY, P): same arithmetic as MODE_F2 of the
+// generic kernel, restructured so that lane j first forms C_k[r] = sum_k' Y_r[k,k'] D_k'[r,j] in
+// registers and then out[i] = sum_k sum_r D_k[r,i] C_k[r]  (|K_a| * P * (|K_b| + P) multiply-adds
+// per block instead of |K_a| |K_b| P^2), all loops unrolled, operators and Y in LDS, the
+// finished blocks staged through LDS and written with a flat coalesced copy (the slab is
+// block-major: [block][element][P*P]).
+// D-table signatures.  SigRuntime reads the (state, operator slot) rows from the kernel
+// arguments; SigDefault<NY> is the reference's default_D layout (src/mgb.jl:595-607)
+//   [u id; u dx; (u dy; (u dz;)) s id]  with the default cone idx = 2:dim+2,
+// i.e. rows 1..NY-1 enter the barrier, row 0 (u itself) does not.  With a compile-time
+// signature every set-membership test below folds away and the block products shrink to the
+// structurally non-zero terms.
+struct SigRuntime {
+    static constexpr bool rt = true;
+    static __device__ __forceinline__ constexpr int state(int) { return 0; }
+    static __device__ __forceinline__ constexpr int stage(int) { return 0; }
+    static __device__ __forceinline__ constexpr int mask() { return 0; }
+};
+template <int NY>
+struct SigDefault {
+    static constexpr bool rt = false;
+    static __device__ __forceinline__ constexpr int state(int k) { return k == NY - 1 ? 1 : 0; }
+    static __device__ __forceinline__ constexpr int stage(int k) { return (k == 0 || k == NY - 1) ? -1 : k - 1; }
+    static __device__ __forceinline__ constexpr int mask() { return ((1 << NY) - 1) & ~1; }
+};
+
+template <int NY, int P, class Sig>
+__global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
+    constexpr int G = (P <= 2) ? 2 : (P <= 4) ? 4 : (P <= 8) ? 8 : (P <= 16) ? 16 : (P <= 32) ? 32 : 64;
+    constexpr int EPB = 256 / G;
+    constexpr int PP = P * P;
+    constexpr int NT = NY * (NY + 1) / 2;
+    extern __shared__ double sh[];
+    const int tid = threadIdx.x;
+    const int el = tid / G;
+    const int r = tid % G;
+    const int nu = Sig::rt ? Pm.nu : 2;
+    auto DST = [&](int k) -> int { return Sig::rt ? Pm.D_state[k] : Sig::state(k); };
+    auto DSG = [&](int k) -> int { return Sig::rt ? Pm.D_stage[k] : Sig::stage(k); };
+    const int ymask = Sig::rt ? Pm.ymask : Sig::mask();
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    const int64_t e = e0 + el;
+    const bool active = (e < Pm.N) && (r < P);
+    const int64_t n = Pm.n;
+    const int64_t node = e * P + r;
+
+    double* zl = sh;                                    // [EPB][nu][G]
+    double* opL = zl + 256 * nu;                        // [nstage][EPB][PP]
+    double* YL = opL + (size_t)Pm.nstage * EPB * PP;    // [EPB][NT][G]
+
+    {
+        int64_t lim = (Pm.N - e0) * PP;
+        if (lim > (int64_t)EPB * PP) lim = (int64_t)EPB * PP;
+        for (int o = 0; o < Pm.nstage; ++o) {
+            const double* src = Pm.stage_ptr[o] + e0 * PP;
+            double* dst = opL + (size_t)o * EPB * PP;
+            for (int i = tid; i < lim; i += 256) dst[i] = src[i];
+        }
+    }
+    if (active) {
+        for (int a = 0; a < nu; ++a) zl[(el * nu + a) * G + r] = Pm.z0[(int64_t)a * n + node];
+    }
+    __syncthreads();
+    const double* opE = opL + (size_t)el * PP;           // + slot * EPB * PP
+    auto OP = [&](int k, int rr, int cc) -> double { return opE[(size_t)DSG(k) * EPB * PP + cc * P + rr]; };
+
+    double y[NY];
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+        double v = 0.0;
+        if (active) {
+            const double* za = zl + (el * nu + DST(k)) * G;
+            if (DSG(k) < 0) v = za[r];
+            else {
+#pragma unroll
+                for (int cc = 0; cc < P; ++cc) v += OP(k, r, cc) * za[cc];
+            }
+        }
+        y[k] = v;
+    }
+    if (active) {
+        double F, g[NY], H[NY * NY];
+        cone_eval<NY, 2>(Pm.cone, node, n, y, F, g, H);
+        const double bwv = Pm.bw ? Pm.bw[node] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NY; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < NY; ++k2) {
+                const double h = H[k * NY + k2];
+                YL[((size_t)el * NT + (k * NY - (k * (k - 1)) / 2 + (k2 - k))) * G + r] =
+                    Pm.bw ? ((bwv == 0.0) ? 0.0 : bwv * h) : Pm.invn * h;
+            }
+    }
+    __syncthreads();
+    const int j = r;
+    const double* Ye = YL + (size_t)el * NT * G;
+    int blk = 0;
+#pragma unroll
+    for (int a = 0; a < nu; ++a)
+#pragma unroll
+        for (int b = a; b < nu; ++b, ++blk) {
+            // lane j owns column j of the block: P contiguous doubles of the block-major slab; a wave
+            // covers 64/G whole blocks, so every cache line is completed within the wave's stores
+            double* dst = Pm.out_hel + (((int64_t)blk * Pm.N + e) * P + j) * (int64_t)P;
+            bool b_all_id = true;
+#pragma unroll
+            for (int k2 = 0; k2 < NY; ++k2)
+                if (DST(k2) == b && ((ymask >> k2) & 1) && DSG(k2) >= 0) b_all_id = false;
+            if (active && b_all_id) {
+                // every operator of state b is the identity: C_k[r] = delta(r, j) * sum_k' Y_j[k,k']
+                double Cd[NY];
+#pragma unroll
+                for (int k = 0; k < NY; ++k) {
+                    double acc = 0.0;
+                    if (DST(k) == a && ((ymask >> k) & 1)) {
+#pragma unroll
+                        for (int k2 = 0; k2 < NY; ++k2) {
+                            if (DST(k2) != b || !((ymask >> k2) & 1)) continue;
+                            const int t = (k <= k2) ? (k * NY - (k * (k - 1)) / 2 + (k2 - k))
+                                                    : (k2 * NY - (k2 * (k2 - 1)) / 2 + (k - k2));
+                            acc += Ye[t * G + j];
+                        }
+                    }
+                    Cd[k] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    double val = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NY; ++k) {
+                        if (DST(k) != a || !((ymask >> k) & 1)) continue;
+                        if (DSG(k) < 0) val += (i == j) ? Cd[k] : 0.0;
+                        else val += OP(k, j, i) * Cd[k];
+                    }
+                    dst[i] = val;
+                }
+            } else if (active) {
+                double C[NY][P];
+#pragma unroll
+                for (int k = 0; k < NY; ++k) {
+                    if (DST(k) != a || !((ymask >> k) & 1)) continue;
+#pragma unroll
+                    for (int rr = 0; rr < P; ++rr) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int k2 = 0; k2 < NY; ++k2) {
+                            if (DST(k2) != b || !((ymask >> k2) & 1)) continue;
+                            const int t = (k <= k2) ? (k * NY - (k * (k - 1)) / 2 + (k2 - k))
+                                                    : (k2 * NY - (k2 * (k2 - 1)) / 2 + (k - k2));
+                            const double yv = Ye[t * G + rr];
+                            if (DSG(k2) < 0) acc += (rr == j) ? yv : 0.0;
+                            else acc += yv * OP(k2, rr, j);
+                        }
+                        C[k][rr] = acc;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    double val = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NY; ++k) {
+                        if (DST(k) != a || !((ymask >> k) & 1)) continue;
+                        if (DSG(k) < 0) val += C[k][i];
+                        else {
+#pragma unroll
+                            for (int rr = 0; rr < P; ++rr) val += OP(k, rr, i) * C[k][rr];
+                        }
+                    }
+                    dst[i] = val;
+                }
+            }
+        }
 }
 
 // ---- reductions ------------------------------------------------------------------------------
@@ -318,6 +486,21 @@ __global__ __launch_bounds__(256) void csr_matvec_wave_kernel(int64_t rows, cons
     if (lane == 0) y[i] = ADD ? y[i] + s : s;
 }
 
+// zfull = z0 + R*s  (src/convex.jl:156): one thread per broken row, so the element kernels
+// read their local values with independent coalesced loads instead of a dependent
+// rowptr -> col/val -> s chain per tile.
+__global__ __launch_bounds__(256) void prolong_kernel(int64_t rows, const int32_t* __restrict__ ptr,
+                                                      const int32_t* __restrict__ col,
+                                                      const double* __restrict__ val,
+                                                      const double* __restrict__ s, const double* __restrict__ z0,
+                                                      double* __restrict__ zfull) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    double v = z0[i];
+    for (int32_t q = ptr[i]; q < ptr[i + 1]; ++q) v += val[q] * s[col[q]];
+    zfull[i] = v;
+}
+
 __global__ __launch_bounds__(256) void step_kernel(const double* __restrict__ x, const double* __restrict__ nn,
                                                    double s, double* __restrict__ xn, int64_t len,
                                                    int32_t* __restrict__ moved) {
@@ -405,7 +588,7 @@ __global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P)
             const double* pb = P.panels + (int64_t)p * ob;
             const bool tr = a > b;
             const int blk = tr ? (b * nu - (b * (b - 1)) / 2 + (a - b)) : (a * nu - (a * (a - 1)) / 2 + (b - a));
-            const double* Hb = P.hel + (e * NB2 + blk) * (int64_t)p * p;
+            const double* Hb = P.hel + ((int64_t)blk * P.N + e) * (int64_t)p * p;
             for (int t = lane; t < p * cb; t += 64) {
                 const int rr = t % p, ib = t / p;
                 double acc = 0.0;
@@ -474,9 +657,53 @@ size_t elem_lds_bytes(const ElemParams& P, int mode) {
     return d * sizeof(double);
 }
 
+template <int NY>
+static bool is_default_signature(const ElemParams& P) {
+    if (P.nu != 2 || P.nD != NY || P.ymask != (((1 << NY) - 1) & ~1)) return false;
+    for (int k = 0; k < NY; ++k) {
+        if (P.D_state[k] != (k == NY - 1 ? 1 : 0)) return false;
+        if (P.D_stage[k] != ((k == 0 || k == NY - 1) ? -1 : k - 1)) return false;
+    }
+    return true;
+}
+
+template <int NY, int PN>
+static bool try_f2_fast(const ElemParams& P, hipStream_t st) {
+    if (P.nD != NY || P.p != PN) return false;
+    for (int k = 0; k < NY; ++k)
+        if (P.D_stage[k] == -2) return false;          // operators not staged: generic path
+    const int G = elem_group(PN);
+    const int EPB = 256 / G;
+    const size_t lds = (256 * (size_t)P.nu + (size_t)P.nstage * EPB * PN * PN + (size_t)EPB * (NY * (NY + 1) / 2) * G) *
+                       sizeof(double);
+    if (lds > 160 * 1024) return false;
+    static bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)elem_f2_fast<NY, PN, SigRuntime>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)elem_f2_fast<NY, PN, SigDefault<NY>>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        return true;
+    }();
+    (void)attr;
+    if (is_default_signature<NY>(P))
+        hipLaunchKernelGGL((elem_f2_fast<NY, PN, SigDefault<NY>>), dim3((unsigned)elem_grid(PN, P.N)), dim3(256), lds, st, P);
+    else
+        hipLaunchKernelGGL((elem_f2_fast<NY, PN, SigRuntime>), dim3((unsigned)elem_grid(PN, P.N)), dim3(256), lds, st, P);
+    return true;
+}
+
 void launch_elem(const ElemParams& P, int mode, hipStream_t st) {
     MGB_REQUIRE(P.p >= 1 && P.p <= 64, "element kernels support 1 <= p <= 64 nodes per element");
     MGB_REQUIRE(P.nD >= 1 && P.nD <= MGBHIP_MAX_ND, "nD out of range");
+    if (mode == MODE_F2) {
+        // compile-time specialisations for the discretisations of the BASELINE configs
+        // (fem1d, fem2d_P2 with/without bubble, fem3d Q1) and their phase-I images
+        if (try_f2_fast<4, 7>(P, st) || try_f2_fast<3, 2>(P, st) || try_f2_fast<5, 8>(P, st) ||
+            try_f2_fast<4, 6>(P, st) || try_f2_fast<7, 7>(P, st) || try_f2_fast<6, 2>(P, st) ||
+            try_f2_fast<8, 8>(P, st) || try_f2_fast<7, 6>(P, st)) {
+            MGB_HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
     static std::once_flag once;
     std::call_once(once, [] {
         set_lds_attr<1>(); set_lds_attr<2>(); set_lds_attr<3>(); set_lds_attr<4>();
@@ -541,6 +768,14 @@ void launch_csr_matvec(int64_t rows, const int32_t* ptr, const int32_t* col, con
         if (add) hipLaunchKernelGGL(csr_matvec_row_kernel<true>, grid, dim3(256), 0, st, rows, ptr, col, val, x, y);
         else hipLaunchKernelGGL(csr_matvec_row_kernel<false>, grid, dim3(256), 0, st, rows, ptr, col, val, x, y);
     }
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_prolong(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val, const double* s,
+                    const double* z0, double* zfull, hipStream_t st) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(prolong_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows, ptr, col, val, s,
+                       z0, zfull);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

@@ -9,6 +9,7 @@ enum ElemMode { MODE_F0 = 0, MODE_F1 = 1, MODE_F2 = 2, MODE_NODE_F = 3, MODE_NOD
 
 struct ElemParams {
     int32_t p, nu, nD, nstage;
+    int32_t ymask;                           // bit k set: row k of y enters some barrier term (else d/dy_k = 0)
     int64_t N, n;
     const double* ops[MGBHIP_MAX_OPS];       // device operator arrays (nullptr = identity)
     const double* stage_ptr[MGBHIP_MAX_OPS]; // operators staged through LDS (distinct, non-identity)
@@ -17,11 +18,7 @@ struct ElemParams {
     int32_t D_stage[MGBHIP_MAX_ND];          // -1 identity, >= 0 slot in stage_ptr, -2 read from HBM
     const double* w;
     const double* c;                         // n x nD (may be nullptr for the node maps)
-    const double* z0;                        // nu*n
-    const double* s;                         // m_J or nullptr
-    const int32_t* Rptr;
-    const int32_t* Rcol;
-    const double* Rval;
+    const double* z0;                        // nu*n: the fine broken-basis iterate z0 + R*s (already prolonged)
     const double* bw;                        // barrier weights or nullptr
     double invn;
     ConeDev cone;
@@ -32,8 +29,8 @@ struct ElemParams {
     double* out_Dz;
 };
 
-// element Hessian slab layout: per element, blocks (a,b), a <= b, in row-major order of
-// the upper block triangle, each p x p column-major.
+// element Hessian slab layout: block-major [block][element][p*p]; blocks (a,b), a <= b, in
+// row-major order of the upper block triangle, each p x p column-major.
 inline int hel_blocks(int nu) { return nu * (nu + 1) / 2; }
 inline int hel_block_index(int a, int b, int nu) { return a * nu - a * (a - 1) / 2 + (b - a); }
 
@@ -52,6 +49,8 @@ int64_t reduce_scratch_doubles(int64_t n);
 // y[i] = sum_j A[i,j] x[j]  (CSR, deterministic; wave-per-row when rows are long)
 void launch_csr_matvec(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val,
                        const double* x, double* y, bool add, bool long_rows, hipStream_t st);
+void launch_prolong(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val, const double* s,
+                    const double* z0, double* zfull, hipStream_t st);
 // xn = x - s*n ; flag[0] |= any(xn != x)
 void launch_step(const double* x, const double* n, double s, double* xn, int64_t len, int32_t* moved,
                  hipStream_t st);

@@ -48,10 +48,11 @@ __device__ __forceinline__ void wave_sync() {
 
 // In-register LDL' of an nb x nb block: lane r holds row r of the lower triangle in a[0..r].
 // 32 x 31 / 2 shuffle + FMA pairs, no memory traffic; nb is wave-uniform.
-__device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NB], int nb, int lane) {
+template <int NBT>
+__device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NBT], int nb, int lane) {
     bool bad = false;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    for (int j = 0; j < NBT; ++j) {
         if (j < nb) {
             const double d = __shfl(a[j], j, 64);
             if (d == 0.0 || !isfinite(d)) bad = true;
@@ -59,7 +60,7 @@ __device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NB], int nb, int lane
             const double aj = a[j];          // this lane's unscaled entry of column j
             const double lr = aj * inv;
 #pragma unroll
-            for (int c = j + 1; c < NB; ++c) {
+            for (int c = j + 1; c < NBT; ++c) {
                 const double v = __shfl(aj, c, 64);      // unscaled entry (c, j)
                 if (c < nb && lane >= c) a[c] -= lr * v;
             }
@@ -72,6 +73,7 @@ __device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NB], int nb, int lane
 // One workgroup per front.  Right-looking LDL' blocked by NB = 32 columns: wave 0 factors the
 // diagonal block in registers (shuffles only), every thread then solves one panel row in
 // registers, and all threads apply the rank-32 update -- 3 workgroup barriers per 32 columns.
+template <int NBT>
 __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                                 const int32_t* __restrict__ children, const int32_t* __restrict__ rel,
                                 const int32_t* __restrict__ a_src, const int32_t* __restrict__ a_dst,
@@ -102,50 +104,50 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
         __syncthreads();
     }
     bool bad = false;
-    for (int j0 = 0; j0 < k; j0 += NB) {
-        const int nb = min(NB, k - j0);
+    for (int j0 = 0; j0 < k; j0 += NBT) {
+        const int nb = min(NBT, k - j0);
         if (tid < 64) {                       // diagonal block in registers
-            double a[NB];
+            double a[NBT];
 #pragma unroll
-            for (int c = 0; c < NB; ++c) a[c] = (tid < nb && c <= tid) ? W[(j0 + tid) + (j0 + c) * m] : 0.0;
-            bad |= wave_ldlt_regs(a, nb, tid);
+            for (int c = 0; c < NBT; ++c) a[c] = (tid < nb && c <= tid) ? W[(j0 + tid) + (j0 + c) * m] : 0.0;
+            bad |= wave_ldlt_regs<NBT>(a, nb, tid);
 #pragma unroll
-            for (int c = 0; c < NB; ++c)
+            for (int c = 0; c < NBT; ++c)
                 if (tid < nb && c <= tid) W[(j0 + tid) + (j0 + c) * m] = a[c];
         }
         __syncthreads();
         {                                     // panel rows: l = (a L11^{-T}) D^{-1}, one row per thread
             const int r = j0 + nb + tid;
             if (r < m) {
-                double a[NB];
+                double a[NBT];
 #pragma unroll
-                for (int c = 0; c < NB; ++c) a[c] = (c < nb) ? W[r + (j0 + c) * m] : 0.0;
+                for (int c = 0; c < NBT; ++c) a[c] = (c < nb) ? W[r + (j0 + c) * m] : 0.0;
 #pragma unroll
-                for (int c = 0; c < NB; ++c) {
+                for (int c = 0; c < NBT; ++c) {
                     if (c < nb) {
                         double v = a[c];
 #pragma unroll
-                        for (int q = 0; q < NB; ++q)
+                        for (int q = 0; q < NBT; ++q)
                             if (q < c) v -= a[q] * W[(j0 + c) + (j0 + q) * m];
                         a[c] = v;
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < NB; ++c)
+                for (int c = 0; c < NBT; ++c)
                     if (c < nb) W[r + (j0 + c) * m] = a[c] / W[(j0 + c) + (j0 + c) * m];
             }
         }
         __syncthreads();
         const int c0 = j0 + nb;
         for (int c = c0 + ty; c < m; c += TYn) {
-            double mult[NB];
+            double mult[NBT];
 #pragma unroll
-            for (int q = 0; q < NB; ++q) mult[q] = (q < nb) ? W[c + (j0 + q) * m] * W[(j0 + q) + (j0 + q) * m] : 0.0;
+            for (int q = 0; q < NBT; ++q) mult[q] = (q < nb) ? W[c + (j0 + q) * m] * W[(j0 + q) + (j0 + q) * m] : 0.0;
             double* Wc = W + c * m;
             for (int r = c + tx; r < m; r += TX) {
                 double acc = 0.0;
 #pragma unroll
-                for (int q = 0; q < NB; ++q)
+                for (int q = 0; q < NBT; ++q)
                     if (q < nb) acc += W[r + (j0 + q) * m] * mult[q];
                 Wc[r] -= acc;
             }
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__
         double a[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c) a[c] = (tid < nb && c <= tid) ? Dk[tid][c] : 0.0;
-        const bool bad = wave_ldlt_regs(a, nb, tid);
+        const bool bad = wave_ldlt_regs<NB>(a, nb, tid);
 #pragma unroll
         for (int c = 0; c < NB; ++c)
             if (tid < nb && c <= tid) Dk[tid][c] = a[c];
@@ -613,7 +615,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
 
     // dynamic LDS above 64 KB needs an explicit opt-in; fall back to the 64 KB classes if refused
     lds_cap = 88;
-    if (hipFuncSetAttribute((const void*)mf_factor_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)mf_factor_small<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             128 * 128 * 8) == hipSuccess)
         lds_cap = 128;
     else
@@ -657,7 +659,6 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     MGB_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
 }
 
-static inline int small_threads(int cls) { return cls <= 16 ? 64 : (cls <= 32 ? 128 : 256); }
 
 void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timers) {
     MGB_REQUIRE(analyzed, "MfSolver::factor before analyze");
@@ -668,9 +669,15 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
             if (L.count == 0) continue;
             if (L.cls) {
                 size_t lds = (size_t)L.cls * L.cls * sizeof(double);
-                hipLaunchKernelGGL(mf_factor_small, dim3(L.count), dim3(small_threads(L.cls)), lds, st, d_fronts.p,
-                                   L.first, d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p,
-                                   d_status.p);
+                if (L.cls <= 16)
+                    hipLaunchKernelGGL(mf_factor_small<8>, dim3(L.count), dim3(64), lds, st, d_fronts.p, L.first,
+                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                else if (L.cls <= 32)
+                    hipLaunchKernelGGL(mf_factor_small<16>, dim3(L.count), dim3(128), lds, st, d_fronts.p, L.first,
+                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                else
+                    hipLaunchKernelGGL(mf_factor_small<32>, dim3(L.count), dim3(256), lds, st, d_fronts.p, L.first,
+                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
             } else {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
                 hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,

@@ -172,6 +172,7 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     const size_t zn = (size_t)P->nu * P->n;
     P->d_z.alloc(zn);
     P->d_z0.alloc(zn);
+    P->d_zfull.alloc(zn);
     P->d_c.alloc((size_t)P->n * P->nD);
     P->d_c0.alloc((size_t)P->n * P->nD);
     P->d_ret.alloc(zn);
@@ -288,8 +289,8 @@ void mgbhip_problem::ensure_plan(int level) {
                                 const int32_t cj = colof(b, e, j);
                                 if (cj < 0) continue;
                                 int64_t src;   // slab index of Hel_ab[i, j] (upper block triangle stored)
-                                if (a <= b) src = ((e * NB + hel_block_index(a, b, nu)) * pp + j) * (int64_t)pp + i;
-                                else src = ((e * NB + hel_block_index(b, a, nu)) * pp + i) * (int64_t)pp + j;
+                                if (a <= b) src = (((int64_t)hel_block_index(a, b, nu) * NE + e) * pp + j) * (int64_t)pp + i;
+                                else src = (((int64_t)hel_block_index(b, a, nu) * NE + e) * pp + i) * (int64_t)pp + j;
                                 emit(find(ci, cj), src);
                             }
                     }
@@ -362,16 +363,23 @@ ElemParams mgbhip_problem::base_params(int level, const double* d_s, const doubl
     ElemParams E;
     std::memset(&E, 0, sizeof(E));
     E.p = p; E.nu = nu; E.nD = nD; E.nstage = nstage; E.N = N; E.n = n;
+    E.ymask = 0;
+    for (int k = 0; k < cone.npieces; ++k)
+        for (int c = 0; c < cone.pc[k].ni; ++c) E.ymask |= 1 << cone.pc[k].idx[c];
+    if (cone.feasibility)
+        for (int k = cone.NC - 1; k < nD; ++k) E.ymask |= 1 << k;
     for (size_t o = 0; o < store->ops.size() && o < MGBHIP_MAX_OPS; ++o) E.ops[o] = store->ops[o].p;
     for (int o = 0; o < nstage; ++o) E.stage_ptr[o] = stage_ptr[o];
     for (int k = 0; k < MGBHIP_MAX_ND; ++k) { E.D_state[k] = D_state[k]; E.D_op[k] = D_op[k]; E.D_stage[k] = D_stage[k]; }
     E.w = store->w.p;
     E.c = d_cc;
+    // z0 + R*s is formed once per evaluation point by a row-parallel kernel (cached on the
+    // (level, s, z) triple by the callers below); the element kernels read the result
     E.z0 = d_zz;
-    E.s = d_s;
-    if (level >= 0) {
+    if (level >= 0 && d_s != nullptr) {
         const Level& L = levels[level];
-        E.Rptr = L.Rptr.p; E.Rcol = L.Rcol.p; E.Rval = L.Rval.p;
+        launch_prolong(L.rows, L.Rptr.p, L.Rcol.p, L.Rval.p, d_s, d_zz, d_zfull.p, stream());
+        E.z0 = d_zfull.p;
     }
     E.bw = has_bw ? bw.p : nullptr;
     E.invn = 1.0 / (double)n;
@@ -386,9 +394,9 @@ ElemParams mgbhip_problem::base_params(int level, const double* d_s, const doubl
 
 double mgbhip_problem::eval_f0(int level, const double* d_s, const double* d_zz, const double* d_cc) {
     hipStream_t st = stream();
-    ElemParams E = base_params(level, d_s, d_zz, d_cc);
     {
         StageScope sc(ctx->timers, "f0");
+        ElemParams E = base_params(level, d_s, d_zz, d_cc);
         launch_elem(E, MODE_F0, st);
         launch_reduce_partials(d_partials.p, elem_grid(p, N), d_scal.p, st);
     }
@@ -401,10 +409,10 @@ double mgbhip_problem::eval_f0(int level, const double* d_s, const double* d_zz,
 
 void mgbhip_problem::eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout) {
     hipStream_t st = stream();
-    ElemParams E = base_params(level, d_s, d_zz, d_cc);
     const Level& L = levels[level];
     {
         StageScope sc(ctx->timers, "f1");
+        ElemParams E = base_params(level, d_s, d_zz, d_cc);
         launch_elem(E, MODE_F1, st);
     }
     {
@@ -417,10 +425,10 @@ void mgbhip_problem::eval_f1(int level, const double* d_s, const double* d_zz, c
 void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc) {
     ensure_plan(level);
     hipStream_t st = stream();
-    ElemParams E = base_params(level, d_s, d_zz, d_cc);
     Level& L = levels[level];
     {
         StageScope sc(ctx->timers, "f2");
+        ElemParams E = base_params(level, d_s, d_zz, d_cc);
         launch_elem(E, MODE_F2, st);
     }
     {

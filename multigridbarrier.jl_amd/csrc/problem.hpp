@@ -68,7 +68,7 @@ struct mgbhip_problem {
     bool has_bw = false;
     std::vector<mgbhip::Level> levels;
     // workspace
-    mgbhip::DevBuf<double> d_z, d_z0, d_c, d_ret, d_hel, d_partials, d_scal, d_scratch, d_nodeF, d_nodeDz;
+    mgbhip::DevBuf<double> d_z, d_z0, d_zfull, d_c, d_ret, d_hel, d_partials, d_scal, d_scratch, d_nodeF, d_nodeDz;
     mgbhip::DevBuf<double> d_x, d_g, d_nv, d_xn, d_gn, d_tmp, d_c0;
     mgbhip::DevBuf<int32_t> d_flag;
     mgbhip::Counters cnt;
