@@ -616,6 +616,10 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     // dynamic LDS above 64 KB needs an explicit opt-in; fall back to the 64 KB classes if refused
     lds_cap = 88;
     if (hipFuncSetAttribute((const void*)mf_factor_small<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            128 * 128 * 8) == hipSuccess &&
+        hipFuncSetAttribute((const void*)mf_factor_small<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            128 * 128 * 8) == hipSuccess &&
+        hipFuncSetAttribute((const void*)mf_factor_small<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             128 * 128 * 8) == hipSuccess)
         lds_cap = 128;
     else
@@ -669,14 +673,17 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
             if (L.count == 0) continue;
             if (L.cls) {
                 size_t lds = (size_t)L.cls * L.cls * sizeof(double);
-                if (L.cls <= 16)
-                    hipLaunchKernelGGL(mf_factor_small<8>, dim3(L.count), dim3(64), lds, st, d_fronts.p, L.first,
+                static const int nbt_mid = [] { const char* e = getenv("MGBHIP_NBT"); return e ? atoi(e) : 8; }();
+                const int threads = L.cls <= 16 ? 64 : (L.cls <= 32 ? 128 : 256);
+                const int nbt = L.cls <= 16 ? 8 : nbt_mid;
+                if (nbt <= 8)
+                    hipLaunchKernelGGL(mf_factor_small<8>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
                                        d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
-                else if (L.cls <= 32)
-                    hipLaunchKernelGGL(mf_factor_small<16>, dim3(L.count), dim3(128), lds, st, d_fronts.p, L.first,
+                else if (nbt <= 16)
+                    hipLaunchKernelGGL(mf_factor_small<16>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
                                        d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
                 else
-                    hipLaunchKernelGGL(mf_factor_small<32>, dim3(L.count), dim3(256), lds, st, d_fronts.p, L.first,
+                    hipLaunchKernelGGL(mf_factor_small<32>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
                                        d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
             } else {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
