@@ -46,6 +46,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Broadcast of a double from a compile-time lane through SGPRs (v_readlane_b32 x 2): cheaper than
+// the LDS-crossbar path of __shfl when the source lane is a constant after unrolling.
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), srclane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // In-register LDL' of an nb x nb block: lane r holds row r of the lower triangle in a[0..r].
 // 32 x 31 / 2 shuffle + FMA pairs, no memory traffic; nb is wave-uniform.
 template <int NBT>
@@ -54,14 +63,14 @@ __device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NBT], int nb, int lan
 #pragma unroll
     for (int j = 0; j < NBT; ++j) {
         if (j < nb) {
-            const double d = __shfl(a[j], j, 64);
+            const double d = readlane_f64(a[j], j);
             if (d == 0.0 || !isfinite(d)) bad = true;
             const double inv = 1.0 / d;
             const double aj = a[j];          // this lane's unscaled entry of column j
             const double lr = aj * inv;
 #pragma unroll
             for (int c = j + 1; c < NBT; ++c) {
-                const double v = __shfl(aj, c, 64);      // unscaled entry (c, j)
+                const double v = readlane_f64(aj, c);     // unscaled entry (c, j)
                 if (c < nb && lane >= c) a[c] -= lr * v;
             }
             if (lane > j) a[j] = lr;
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256) void mf_forward_small(const FrontDev* __restri
         const double* Lj = Fm + (int64_t)j * m;
         const double l0 = (lane > j && lane < m) ? Lj[lane] : 0.0;
         const double l1 = (r1 > j && r1 < m) ? Lj[r1] : 0.0;
-        const double tj = (j < 64) ? __shfl(t0, j, 64) : __shfl(t1, j - 64, 64);
+        const double tj = (j < 64) ? readlane_f64(t0, j) : readlane_f64(t1, j - 64);   // j is wave-uniform
         t0 -= l0 * tj;
         t1 -= l1 * tj;
     }
@@ -304,6 +313,7 @@ __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__
                                                     double* __restrict__ arena, double* __restrict__ dscr,
                                                     int32_t* __restrict__ status) {
     __shared__ double Dk[NB][NB + 1];
+    __shared__ double rinv[NB];
     const FrontDev F = fr[first + blockIdx.y];
     const int m = F.m, k = F.k;
     if (j0 >= k) return;
@@ -324,7 +334,10 @@ __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__
         const bool bad = wave_ldlt_regs<NB>(a, nb, tid);
 #pragma unroll
         for (int c = 0; c < NB; ++c)
-            if (tid < nb && c <= tid) Dk[tid][c] = a[c];
+            if (tid < nb && c <= tid) {
+                Dk[tid][c] = a[c];
+                if (c == tid) rinv[tid] = 1.0 / a[c];
+            }
         if (bad && tid == 0 && blockIdx.x == 0) atomicOr(status, 1);
     }
     __syncthreads();
@@ -356,7 +369,7 @@ __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__
         }
 #pragma unroll
         for (int c = 0; c < NB; ++c)
-            if (c < nb) W[r + (int64_t)(j0 + c) * m] = a[c] / Dk[c][c];
+            if (c < nb) W[r + (int64_t)(j0 + c) * m] = a[c] * rinv[c];
     }
 }
 
@@ -490,9 +503,12 @@ __global__ __launch_bounds__(256) void mf_fwd_big_step(const FrontDev* __restric
     __syncthreads();
     if (tid < 64) {
         double v = (tid < nb) ? t[j0 + tid] : 0.0;
-        for (int c = 0; c < nb; ++c) {
-            const double tc = __shfl(v, c, 64);
-            if (tid > c && tid < nb) v -= Dk[tid][c] * tc;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            if (c < nb) {
+                const double tc = readlane_f64(v, c);
+                if (tid > c && tid < nb) v -= Dk[tid][c] * tc;
+            }
         }
         if (tid < nb) {
             yb[tid] = v;
@@ -565,9 +581,12 @@ __global__ __launch_bounds__(256) void mf_bwd_big_step(const FrontDev* __restric
     __syncthreads();
     if (tid < 64) {
         double v = (tid < nb) ? t[j0 + tid] : 0.0;
-        for (int c = nb - 1; c >= 0; --c) {
-            const double xc = __shfl(v, c, 64);
-            if (tid < c) v -= Dk[c][tid] * xc;
+#pragma unroll
+        for (int c = NB - 1; c >= 0; --c) {
+            if (c < nb) {
+                const double xc = readlane_f64(v, c);
+                if (tid < c) v -= Dk[c][tid] * xc;
+            }
         }
         if (tid < nb) {
             xb[tid] = v;
