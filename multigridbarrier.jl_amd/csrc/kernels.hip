@@ -16,6 +16,7 @@
 #include <mutex>
 
 #include "kernels.hpp"
+#include "dense.hpp"
 
 namespace mgbhip {
 
@@ -643,6 +644,7 @@ int elem_group(int p) {
 }
 
 int64_t elem_grid(int p, int64_t N) {
+    if (p > 64) return dense_grid((int64_t)p * N);
     const int epb = 256 / elem_group(p);
     return (N + epb - 1) / epb;
 }
@@ -692,6 +694,10 @@ static bool try_f2_fast(const ElemParams& P, hipStream_t st) {
 }
 
 void launch_elem(const ElemParams& P, int mode, hipStream_t st) {
+    if (P.p > 64) {      // one dense spectral element: GEMV + node kernel path (dense.hip)
+        launch_dense_eval(P, mode, st);
+        return;
+    }
     MGB_REQUIRE(P.p >= 1 && P.p <= 64, "element kernels support 1 <= p <= 64 nodes per element");
     MGB_REQUIRE(P.nD >= 1 && P.nD <= MGBHIP_MAX_ND, "nD out of range");
     if (mode == MODE_F2) {

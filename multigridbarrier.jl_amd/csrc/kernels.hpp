@@ -27,6 +27,8 @@ struct ElemParams {
     double* out_hel;                         // f2: element Hessian blocks
     double* out_F;                           // node maps
     double* out_Dz;
+    double* dn_Dz;                           // dense path (p > 64, N = 1): n x nD workspace for D*z
+    double* dn_Y;                            // dense path: n x nD (f1) / n x nD(nD+1)/2 (f2) node weights
 };
 
 // element Hessian slab layout: block-major [block][element][p*p]; blocks (a,b), a <= b, in

@@ -1,6 +1,7 @@
 // problem.cpp -- native_to_device for one (AMG, Convex) pair, the per-level R'HR assembly
 // plans, and the device-resident f0/f1/f2/solve primitives behind the C ABI.
 #include "problem.hpp"
+#include "dense.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -47,6 +48,9 @@ static void upload_csr(const mgbhip_csr& R, Level& L, hipStream_t st) {
         }
     for (int64_t j = 0; j < R.cols; ++j) maxrow = std::max(maxrow, tp[j + 1] - tp[j]);
     L.T_long = maxrow > 64;
+    int32_t maxr = 0;
+    for (int64_t i = 0; i < R.rows; ++i) maxr = std::max(maxr, L.hRptr[i + 1] - L.hRptr[i]);
+    L.R_long = maxr > 64;
     L.Tptr.upload(tp, st);
     L.Tcol.upload(tc.data(), tc.size(), st);
     L.Tval.upload(tv.data(), tv.size(), st);
@@ -63,8 +67,10 @@ static const double* upload_grid(mgbhip_problem* P, const double* h, size_t coun
 
 mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mgbhip_problem* share) {
     MGB_REQUIRE(ctx && d, "null argument");
-    MGB_REQUIRE(d->p >= 1 && d->p <= 64, "nodes per element must be in 1..64");
-    MGB_REQUIRE(d->N >= 1, "need at least one element");
+    MGB_REQUIRE(d->p >= 1 && d->N >= 1, "need at least one element and one node per element");
+    // p <= 64: element kernels.  p > 64 is accepted for ONE element only: dense spectral operators.
+    MGB_REQUIRE(d->p <= 64 || d->N == 1, "more than 64 nodes per element is supported for a single dense element only");
+    MGB_REQUIRE(d->p <= 16384, "dense element too large");
     MGB_REQUIRE(d->nu >= 1 && d->nu <= MGBHIP_MAX_NU, "state components out of range");
     MGB_REQUIRE(d->nD >= 1 && d->nD <= MGBHIP_MAX_ND, "D rows out of range");
     MGB_REQUIRE(d->n_ops >= 1 && d->n_ops <= MGBHIP_MAX_OPS, "operator count out of range");
@@ -77,6 +83,7 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     P->n = (int64_t)d->p * d->N;
     P->nu = d->nu;
     P->nD = d->nD;
+    P->dense = d->p > 64;
     MGB_REQUIRE((int64_t)P->nu * P->n < INT32_MAX, "problem too large for 32-bit row indices");
     hipStream_t st = ctx->stream;
     const size_t blk = (size_t)d->p * d->p * d->N;
@@ -99,7 +106,7 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     int slot_of_op[MGBHIP_MAX_OPS];
     for (int o = 0; o < MGBHIP_MAX_OPS; ++o) slot_of_op[o] = -1;
     const int G = elem_group(P->p);
-    const int EPB = 256 / G;
+    const int EPB = P->dense ? 1 : 256 / G;
     for (int k = 0; k < d->nD; ++k) {
         MGB_REQUIRE(d->D_state[k] >= 0 && d->D_state[k] < d->nu, "D row references a missing state variable");
         MGB_REQUIRE(d->D_op[k] >= 0 && d->D_op[k] < d->n_ops, "D row references a missing operator");
@@ -110,7 +117,7 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
         if (slot_of_op[o] < 0) {
             // stage through LDS while the operator tiles of one workgroup stay under 64 KB
             size_t bytes = (size_t)(P->nstage + 1) * EPB * P->p * P->p * sizeof(double);
-            if (bytes <= 64 * 1024) {
+            if (!P->dense && bytes <= 64 * 1024) {
                 slot_of_op[o] = P->nstage;
                 P->stage_ptr[P->nstage++] = P->store->ops[o].p;
             } else {
@@ -176,7 +183,13 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     P->d_c.alloc((size_t)P->n * P->nD);
     P->d_c0.alloc((size_t)P->n * P->nD);
     P->d_ret.alloc(zn);
-    P->d_hel.alloc((size_t)P->N * hel_blocks(P->nu) * P->p * P->p);
+    if (P->dense) {
+        P->d_dnDz.alloc((size_t)P->n * P->nD);
+        P->d_dnY.alloc((size_t)P->n * (P->nD * (P->nD + 1) / 2));
+        P->d_hel.alloc(1);
+    } else {
+        P->d_hel.alloc((size_t)P->N * hel_blocks(P->nu) * P->p * P->p);
+    }
     P->d_partials.alloc((size_t)elem_grid(P->p, P->N));
     P->d_scal.alloc(16);
     P->d_scratch.alloc((size_t)reduce_scratch_doubles(std::max<int64_t>(mmax, (int64_t)zn)));
@@ -193,9 +206,61 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
 // CUDA twin builds dense panels + Int32 scatter maps, block_ops.jl:251-411)
 // ---------------------------------------------------------------------------------------------
 
+// Dense spectral level: the Hessian is a full m x m matrix (its CSR image is the row-major
+// array itself), H = DR' * (Ybar * DR) with DR_k = D_k * R[rows of state(k)] formed once here.
+void mgbhip_problem::ensure_plan_dense(int level) {
+    Level& L = levels[level];
+    hipStream_t st = stream();
+    const int64_t m = L.m, nn = n;
+    MGB_REQUIRE(m * m < (int64_t)INT32_MAX, "dense Hessian exceeds 32-bit indexing");
+    L.hHptr.resize(m + 1);
+    L.hHcol.resize((size_t)(m * m));
+    for (int64_t i = 0; i <= m; ++i) L.hHptr[i] = (int32_t)(i * m);
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < m; ++j) L.hHcol[i * m + j] = (int32_t)j;
+    L.nnz = m * m;
+    L.Hptr.upload(L.hHptr, st);
+    L.Hcol.upload(L.hHcol, st);
+    L.Hval.alloc((size_t)std::max<int64_t>(L.nnz, 1));
+    L.selection = false;
+    const int64_t ld = (int64_t)nD * nn;
+    L.denseDR.alloc((size_t)std::max<int64_t>(ld * m, 1));
+    L.denseW.alloc((size_t)std::max<int64_t>(ld * m, 1));
+    MGB_HIP_CHECK(hipMemsetAsync(L.denseW.p, 0, sizeof(double) * (size_t)std::max<int64_t>(ld * m, 1), st));
+    std::vector<DevBuf<double>> Rd(nu);          // dense R blocks per state (n x m, column-major)
+    std::vector<double> host((size_t)(nn * m));
+    DevBuf<double> opT;
+    opT.alloc((size_t)(nn * nn));
+    for (int k = 0; k < nD; ++k) {
+        const int a = D_state[k];
+        if (!Rd[a].p) {
+            std::fill(host.begin(), host.end(), 0.0);
+            for (int64_t r = 0; r < nn; ++r) {
+                const int64_t row = (int64_t)a * nn + r;
+                for (int32_t q = L.hRptr[row]; q < L.hRptr[row + 1]; ++q) host[(size_t)(r + nn * L.hRcol[q])] += L.hRval[q];
+            }
+            Rd[a].upload(host.data(), host.size(), st);
+            MGB_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        double* dst = L.denseDR.p + (int64_t)k * nn;
+        const double* op = store->ops[D_op[k]].p;
+        if (m == 0) continue;
+        if (store->identity[D_op[k]]) {
+            MGB_HIP_CHECK(hipMemcpy2DAsync(dst, sizeof(double) * ld, Rd[a].p, sizeof(double) * nn, sizeof(double) * nn,
+                                           (size_t)m, hipMemcpyDeviceToDevice, st));
+        } else {
+            launch_dense_transpose((int)nn, op, opT.p, st);
+            launch_dense_gemm_tn((int)nn, (int)m, (int)nn, opT.p, nn, nullptr, Rd[a].p, nn, dst, ld, false, false, st);
+        }
+    }
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    L.planned = true;
+}
+
 void mgbhip_problem::ensure_plan(int level) {
     Level& L = levels[level];
     if (L.planned) return;
+    if (dense) { ensure_plan_dense(level); return; }
     hipStream_t st = stream();
     const int64_t NE = N;
     const int pp = p;
@@ -378,7 +443,12 @@ ElemParams mgbhip_problem::base_params(int level, const double* d_s, const doubl
     E.z0 = d_zz;
     if (level >= 0 && d_s != nullptr) {
         const Level& L = levels[level];
-        launch_prolong(L.rows, L.Rptr.p, L.Rcol.p, L.Rval.p, d_s, d_zz, d_zfull.p, stream());
+        if (L.R_long) {      // dense prolongation rows: wave per row
+            MGB_HIP_CHECK(hipMemcpyAsync(d_zfull.p, d_zz, sizeof(double) * (size_t)L.rows, hipMemcpyDeviceToDevice, stream()));
+            launch_csr_matvec(L.rows, L.Rptr.p, L.Rcol.p, L.Rval.p, d_s, d_zfull.p, true, true, stream());
+        } else {
+            launch_prolong(L.rows, L.Rptr.p, L.Rcol.p, L.Rval.p, d_s, d_zz, d_zfull.p, stream());
+        }
         E.z0 = d_zfull.p;
     }
     E.bw = has_bw ? bw.p : nullptr;
@@ -389,6 +459,8 @@ ElemParams mgbhip_problem::base_params(int level, const double* d_s, const doubl
     E.out_hel = d_hel.p;
     E.out_F = d_nodeF.p;
     E.out_Dz = nullptr;
+    E.dn_Dz = d_dnDz.p;
+    E.dn_Y = d_dnY.p;
     return E;
 }
 
@@ -426,14 +498,30 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
     ensure_plan(level);
     hipStream_t st = stream();
     Level& L = levels[level];
+    int E_ymask = 0;
     {
         StageScope sc(ctx->timers, "f2");
         ElemParams E = base_params(level, d_s, d_zz, d_cc);
+        E_ymask = E.ymask;
         launch_elem(E, MODE_F2, st);
     }
     {
         StageScope sc(ctx->timers, "assemble");
-        if (L.selection) {
+        if (dense) {
+            // rows of y that enter the barrier form a contiguous range in every supported D
+            // layout; rows outside it have zero weights and are skipped in the product
+            int klo = nD, khi = -1;
+            for (int k = 0; k < nD; ++k)
+                if ((E_ymask >> k) & 1) { klo = std::min(klo, k); khi = std::max(khi, k); }
+            const int64_t ld = (int64_t)nD * n;
+            if (khi < klo) {
+                MGB_HIP_CHECK(hipMemsetAsync(L.Hval.p, 0, sizeof(double) * (size_t)L.nnz, st));
+            } else {
+                launch_dense_weight(nD, klo, khi, n, L.m, ld, L.denseDR.p, d_dnY.p, L.denseW.p, st);
+                launch_dense_gemm_tn((int)L.m, (int)L.m, (int)((khi - klo + 1) * n), L.denseDR.p + (int64_t)klo * n, ld,
+                                     nullptr, L.denseW.p + (int64_t)klo * n, ld, L.Hval.p, L.m, false, true, st);
+            }
+        } else if (L.selection) {
             launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, d_hel.p, L.Hval.p, L.long_lists, st);
         } else {
             PanelParams PP;

@@ -32,7 +32,7 @@ struct Level {
     std::vector<double> hRval;
     DevBuf<int32_t> Rptr, Rcol, Tptr, Tcol;
     DevBuf<double> Rval, Tval;
-    bool T_long = false;
+    bool T_long = false, R_long = false;
     // assembly plan for H = R' H_blk R (reference: BlockAssemblyPlan, src/BlockMatrices.jl:281-491)
     bool planned = false;
     bool selection = false;               // every row of R has at most one entry, equal to 1
@@ -43,6 +43,8 @@ struct Level {
     int32_t cmax = 1;
     bool long_lists = false;
     int64_t nnz = 0;
+    // dense (spectral) levels: DR = [D_k R_{state(k)}]_k stacked ((nD*n) x m) and W = Ybar * DR
+    DevBuf<double> denseDR, denseW;
     MfSolver solver;
     bool have_H = false, factored = false;
 };
@@ -58,6 +60,7 @@ struct mgbhip_problem {
     mgbhip_ctx* ctx = nullptr;
     int32_t p = 0, nu = 0, nD = 0;
     int64_t N = 0, n = 0;
+    bool dense = false;                    // one dense spectral element (p > 64): dense.hip path
     std::shared_ptr<mgbhip::OpStore> store;
     int32_t D_state[MGBHIP_MAX_ND], D_op[MGBHIP_MAX_ND], D_stage[MGBHIP_MAX_ND];
     int32_t nstage = 0;
@@ -68,7 +71,7 @@ struct mgbhip_problem {
     bool has_bw = false;
     std::vector<mgbhip::Level> levels;
     // workspace
-    mgbhip::DevBuf<double> d_z, d_z0, d_zfull, d_c, d_ret, d_hel, d_partials, d_scal, d_scratch, d_nodeF, d_nodeDz;
+    mgbhip::DevBuf<double> d_z, d_z0, d_zfull, d_c, d_ret, d_hel, d_partials, d_scal, d_scratch, d_nodeF, d_nodeDz, d_dnDz, d_dnY;
     mgbhip::DevBuf<double> d_x, d_g, d_nv, d_xn, d_gn, d_tmp, d_c0;
     mgbhip::DevBuf<int32_t> d_flag;
     mgbhip::Counters cnt;
@@ -76,6 +79,7 @@ struct mgbhip_problem {
     mgbhip::ElemParams base_params(int level, const double* d_s, const double* d_zz, const double* d_cc) const;
     hipStream_t stream() const { return ctx->stream; }
     void ensure_plan(int level);
+    void ensure_plan_dense(int level);
     double eval_f0(int level, const double* d_s, const double* d_zz, const double* d_cc);
     void eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
     void eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc);

@@ -422,13 +422,12 @@ class DeviceProblem:
 
 def dense_as_block(M: AMG) -> AMG:
     """Spectral geometries carry dense operators (one notional element, reference:
-    src/spectral1d.jl:100-108).  With N = 1 and p = n_nodes <= 64 a dense operator *is* a
-    single element block, so small spectral problems run through the same element kernels."""
+    src/spectral1d.jl:100-108).  A dense operator *is* a single element block (N = 1,
+    p = n_nodes): up to 64 nodes it runs through the element kernels, above that the library
+    switches to its dense path (GEMV + node kernel + fp64 MFMA GEMM, csrc/dense.hip)."""
     if isinstance(M.D_fine[0], BlockColumn):
         return M
     n = M.w.size
-    if n > 64:
-        raise NotImplementedError("dense-operator problems with more than 64 nodes need the dense MFMA path")
     geom = M.geometry
     ops = {k: BlockDiag(np.asarray(v, dtype=np.float64).reshape(n, n, 1)) for k, v in geom.operators.items()}
     from dataclasses import replace

@@ -51,7 +51,10 @@ def _check_primitives(P, Mo, Q, c, z0, rng, scale=1e-3, solve=True):
 @pytest.mark.parametrize("spec", [
     ("fem2d_P2", dict(L=3), 1.5), ("fem2d_P2", dict(L=3), 1.0), ("fem2d_P2", dict(L=2), 4.0),
     ("fem1d", dict(nodes=9), 2.0), ("fem3d", dict(L=2, k=1), 1.5), ("fem2d_Q2", dict(L=2), 1.5),
-    ("spectral1d", dict(n=6), 1.5), ("spectral2d", dict(n=4), 1.0)])
+    ("spectral1d", dict(n=6), 1.5), ("spectral2d", dict(n=4), 1.0),
+    # > 64 nodes: dense path (GEMV + node kernel + fp64 MFMA GEMM), ragged 64x64 tile edges
+    ("spectral2d", dict(n=10), 1.5), ("spectral1d", dict(n=80, scale=1e-6), 1.0),
+    ("spectral2d", dict(n=13, scale=1e-5), 1.0)])
 def test_barrier_closures_and_solve_match_oracle(spec):
     kind, kw, p = spec
     if kind == "fem2d_P2":
@@ -70,7 +73,7 @@ def test_barrier_closures_and_solve_match_oracle(spec):
     D = _device(prob)
     try:
         _check_primitives(D.main, O.OracleAMG(prob.M[0]), prob.Q, 0.1 * prob.f, stacked(prob.g),
-                          np.random.default_rng(7))
+                          np.random.default_rng(7), scale=kw.get("scale", 1e-3))
     finally:
         D.close()
 
@@ -211,6 +214,18 @@ def test_fem3d_p4_config4_family_matches_oracle():
     sol = m.mgb_solve(prob)
     so = O.mgb_solve(prob)
     assert np.abs(sol.z - so["z"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("n,p", [(10, 1.5), (12, 1.0)])
+def test_spectral2d_dense_path_config5_family_matches_oracle(n, p):
+    """spectral2d with more than 64 nodes (BASELINE configs[4] family): dense operators, dense
+    coarse-to-fine Hessians on the fp64 matrix cores, dense LDL' -- against the CPU oracle."""
+    prob = m.assemble(m.amg(m.spectral2d(n=n)), p=p)
+    sol = m.mgb_solve(prob)
+    so = O.mgb_solve(prob)
+    # the last finalize iteration is decided by a roundoff-level decrement: allow one step either way
+    assert abs(int(sol.SOL_main["its"].sum()) - int(so["SOL_main"]["its"].sum())) <= 2
+    assert np.abs(sol.z - so["z"]).max() < 1e-8
 
 
 def test_config2_size_properties_and_determinism():

@@ -1,0 +1,19 @@
+"""Time the dense (spectral) path: python tools/gpu_spectral.py n p  (BASELINE configs[4] family)."""
+import sys, time, json
+import numpy as np
+sys.path.insert(0, ".")
+import mgb_amd as m
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+p = float(sys.argv[2]) if len(sys.argv) > 2 else 1.5
+t0 = time.time()
+prob = m.assemble(m.amg(m.spectral2d(n=n)), p=p)
+print("setup", round(time.time() - t0, 2), "s; levels", [R.shape for R in prob.M[0].R_fine], flush=True)
+for rep in range(2):
+    t0 = time.time()
+    sol = m.mgb_solve(prob)
+    dt = time.time() - t0
+    its = int(sol.SOL_main["its"].sum())
+    print(f"rep {rep}: its {its} wall {dt:.3f}s core {sol.SOL_main['t_elapsed']:.3f}s  it/s {its/sol.SOL_main['t_elapsed']:.1f}", flush=True)
+st = sol.stage_ms if hasattr(sol, "stage_ms") else None
+print(json.dumps(st) if st else "")
