@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void mf_big_assemble(const FrontDev* __restric
 // has a single active workgroup, which writes in place.
 __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__ fr, int32_t first, int j0,
                                                     double* __restrict__ arena, double* __restrict__ dscr,
-                                                    int32_t* __restrict__ status) {
+                                                    int32_t* __restrict__ status, int do_diag) {
     __shared__ double Dk[NB][NB + 1];
     __shared__ double rinv[NB];
     const FrontDev F = fr[first + blockIdx.y];
@@ -321,42 +321,56 @@ __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__
     const int r0 = j0 + nb + blockIdx.x * TR;
     if (blockIdx.x > 0 && r0 >= m) return;
     double* W = arena + F.F_off;
+    double* slot = dscr + ((int64_t)blockIdx.y * 2 + ((j0 / NB) & 1)) * (NB * NB);
     const int tid = threadIdx.x;
-    for (int i = tid; i < nb * nb; i += 256) {
-        const int r = i % nb, c = i / nb;
-        Dk[r][c] = (r >= c) ? W[(j0 + r) + (int64_t)(j0 + c) * m] : 0.0;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        double a[NB];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = (tid < nb && c <= tid) ? Dk[tid][c] : 0.0;
-        const bool bad = wave_ldlt_regs<NB>(a, nb, tid);
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
-            if (tid < nb && c <= tid) {
-                Dk[tid][c] = a[c];
-                if (c == tid) rinv[tid] = 1.0 / a[c];
-            }
-        if (bad && tid == 0 && blockIdx.x == 0) atomicOr(status, 1);
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        const bool last = (j0 + nb >= m);          // no panel rows, no trailing block: write home
-        double* dst = last ? nullptr : dscr + (int64_t)blockIdx.y * (NB * NB);
-        for (int i = tid; i < nb * nb; i += 256) {
-            const int r = i % nb, c = i / nb;
-            if (r >= c) {
-                if (last) W[(j0 + r) + (int64_t)(j0 + c) * m] = Dk[r][c];
-                else dst[r + NB * c] = Dk[r][c];
-            }
-        }
-    }
+    const bool last = (j0 + nb >= m);              // no panel rows, no trailing block: write home
+    // this thread's panel row: issue the loads before the diagonal block is ready
     const int r = r0 + tid;
+    double a[NB];
     if (r < m) {
-        double a[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c) a[c] = (c < nb) ? W[r + (int64_t)(j0 + c) * m] : 0.0;
+    }
+    if (do_diag) {
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int rr = i % NB, c = i / NB;
+            Dk[rr][c] = (rr >= c && rr < nb) ? W[(j0 + rr) + (int64_t)(j0 + c) * m] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double d[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) d[c] = (tid < nb && c <= tid) ? Dk[tid][c] : 0.0;
+            const bool bad = wave_ldlt_regs<NB>(d, nb, tid);
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (tid < nb && c <= tid) Dk[tid][c] = d[c];
+            if (bad && tid == 0 && blockIdx.x == 0) atomicOr(status, 1);
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && !last) {
+            for (int i = tid; i < NB * NB; i += 256) {
+                const int rr = i % NB, c = i / NB;
+                if (rr >= c && rr < nb) slot[rr + NB * c] = Dk[rr][c];
+            }
+        }
+    } else {
+        // factored by the previous step's update kernel (look-ahead)
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int rr = i % NB, c = i / NB;
+            Dk[rr][c] = (rr >= c && rr < nb) ? slot[rr + NB * c] : 0.0;
+        }
+        __syncthreads();
+    }
+    if (tid < nb) rinv[tid] = 1.0 / Dk[tid][tid];
+    if (blockIdx.x == 0 && last) {
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int rr = i % NB, c = i / NB;
+            if (rr >= c && rr < nb) W[(j0 + rr) + (int64_t)(j0 + c) * m] = Dk[rr][c];
+        }
+    }
+    __syncthreads();
+    if (r < m) {
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             if (c < nb) {
@@ -377,10 +391,12 @@ __global__ __launch_bounds__(256) void mf_big_panel(const FrontDev* __restrict__
 // C[r, c] -= sum_q L[r, q] d_q L[c, q], 64 x 64 tiles of the lower triangle, 4 x 4 per thread.
 // Tile 0 also copies the factored diagonal block from the scratch slot to its home.
 __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict__ fr, int32_t first, int j0,
-                                                     double* __restrict__ arena, const double* __restrict__ dscr) {
+                                                     double* __restrict__ arena, double* __restrict__ dscr,
+                                                     int32_t* __restrict__ status) {
     __shared__ double Pi[NB][ST + 1];
     __shared__ double Qj[NB][ST + 1];
     __shared__ double dq[NB];
+    __shared__ double Dn[NB][NB + 1];      // look-ahead: the next diagonal block (tile 0 only)
     const FrontDev F = fr[first + blockIdx.y];
     const int m = F.m, k = F.k;
     if (j0 >= k) return;
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
     const int tj = lin - ti * (ti + 1) / 2;
     if (ti >= T) return;
     double* W = arena + F.F_off;
-    const double* src = dscr + (int64_t)blockIdx.y * (NB * NB);
+    const double* src = dscr + ((int64_t)blockIdx.y * 2 + ((j0 / NB) & 1)) * (NB * NB);
     const int tid = threadIdx.x;
     if (tid < nb) dq[tid] = src[tid + NB * tid];
     if (lin == 0) {
@@ -436,7 +452,28 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int r = rbase + tx + 16 * a;
-            if (r < m && r >= c) W[r + (int64_t)c * m] -= acc[a][b];
+            if (r < m && r >= c) {
+                const double val = W[r + (int64_t)c * m] - acc[a][b];
+                W[r + (int64_t)c * m] = val;
+                if (lin == 0 && r - j1 < NB && c - j1 < NB) Dn[r - j1][c - j1] = val;
+            }
+        }
+    }
+    // Look-ahead: tile 0 holds the next diagonal block; factor it here, off the critical path of
+    // the other tiles, so that the next panel kernel starts with its row solves at once.
+    if (lin == 0 && j1 < k) {
+        const int nbn = min(NB, k - j1);
+        double* nslot = dscr + ((int64_t)blockIdx.y * 2 + ((j1 / NB) & 1)) * (NB * NB);
+        __syncthreads();
+        if (tid < 64) {
+            double d[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) d[c] = (tid < nbn && c <= tid) ? Dn[tid][c] : 0.0;
+            const bool bad = wave_ldlt_regs<NB>(d, nbn, tid);
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (tid < nbn && c <= tid) nslot[tid + NB * c] = d[c];
+            if (bad && tid == 0) atomicOr(status, 1);
         }
     }
 }
@@ -677,7 +714,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     for (auto& lev : level_launches)
         for (auto& L : lev)
             if (!L.cls) max_big = std::max(max_big, L.count);
-    d_dscr.alloc((size_t)max_big * NB * NB);
+    d_dscr.alloc((size_t)max_big * 2 * NB * NB);
     analyzed = true;
     MGB_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
 }
@@ -712,12 +749,12 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                     const int rem = L.max_m - j0;                // rows from the panel start, at most
                     const dim3 gp(std::max(1, (rem - 1 + TR - 1) / TR), L.count);
                     hipLaunchKernelGGL(mf_big_panel, gp, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p,
-                                       d_dscr.p, d_status.p);
+                                       d_dscr.p, d_status.p, j0 == 0 ? 1 : 0);
                     const int T = (rem - 1 + ST - 1) / ST;       // trailing tiles (upper bound)
                     if (T > 0) {
                         const dim3 gu(T * (T + 1) / 2, L.count);
                         hipLaunchKernelGGL(mf_big_update, gu, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p,
-                                           d_dscr.p);
+                                           d_dscr.p, d_status.p);
                     }
                 }
             }

@@ -1,7 +1,7 @@
 """Time the dense (spectral) path: python tools/gpu_spectral.py n p  (BASELINE configs[4] family)."""
 import sys, time, json
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import mgb_amd as m
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
