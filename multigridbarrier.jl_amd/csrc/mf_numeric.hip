@@ -55,6 +55,18 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// 1/d by v_rcp_f64 and two Newton steps (the pivot chain of the in-register LDL' is latency
+// bound; the full IEEE division sequence is twice as long).  Error < 1 ulp of the quotient, and
+// LDL' is backward stable under any such perturbation of the multipliers.
+__device__ __forceinline__ double fast_recip(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    e = __builtin_fma(-d, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    return x;
+}
+
 // In-register LDL' of an nb x nb block: lane r holds row r of the lower triangle in a[0..r].
 // 32 x 31 / 2 shuffle + FMA pairs, no memory traffic; nb is wave-uniform.
 template <int NBT>
@@ -65,7 +77,7 @@ __device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NBT], int nb, int lan
         if (j < nb) {
             const double d = readlane_f64(a[j], j);
             if (d == 0.0 || !isfinite(d)) bad = true;
-            const double inv = 1.0 / d;
+            const double inv = fast_recip(d);
             const double aj = a[j];          // this lane's unscaled entry of column j
             const double lr = aj * inv;
 #pragma unroll
@@ -403,15 +415,52 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
     const int nb = min(NB, k - j0);
     const int j1 = j0 + nb;
     const int T = (m - j1 + ST - 1) / ST;
+    const int tid = threadIdx.x;
+    double* W = arena + F.F_off;
+    const double* src = dscr + ((int64_t)blockIdx.y * 2 + ((j0 / NB) & 1)) * (NB * NB);
+    const bool look = j1 < k;                  // a next panel exists: its diagonal block is factored here
+    if (blockIdx.x == gridDim.x - 1) {
+        // Look-ahead workgroup: update only the next diagonal block (nbn x nbn corner of tile 0)
+        // and factor it, concurrently with the trailing tiles, so the next panel kernel starts
+        // with its row solves at once.  Tile 0 leaves that corner alone (it is rewritten from
+        // the scratch slot when the factored block goes home), so there is no race on W.
+        if (!look) return;
+        const int nbn = min(NB, k - j1);
+        double* nslot = dscr + ((int64_t)blockIdx.y * 2 + ((j1 / NB) & 1)) * (NB * NB);
+        if (tid < nb) dq[tid] = src[tid + NB * tid];
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int rr = i % NB, q = i / NB;
+            Pi[q][rr] = (rr < nbn && q < nb) ? W[(j1 + rr) + (int64_t)(j0 + q) * m] : 0.0;
+        }
+        __syncthreads();
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int rr = i % NB, c = i / NB;
+            if (rr >= c && rr < nbn) {
+                double acc = 0.0;
+#pragma unroll 8
+                for (int q = 0; q < NB; ++q) acc += Pi[q][rr] * (Pi[q][c] * dq[q < nb ? q : 0]);
+                Dn[rr][c] = W[(j1 + rr) + (int64_t)(j1 + c) * m] - acc;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double d[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) d[c] = (tid < nbn && c <= tid) ? Dn[tid][c] : 0.0;
+            const bool bad = wave_ldlt_regs<NB>(d, nbn, tid);
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (tid < nbn && c <= tid) nslot[tid + NB * c] = d[c];
+            if (bad && tid == 0) atomicOr(status, 1);
+        }
+        return;
+    }
     const int lin = blockIdx.x;
     int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
     while (ti * (ti + 1) / 2 > lin) --ti;
     const int tj = lin - ti * (ti + 1) / 2;
     if (ti >= T) return;
-    double* W = arena + F.F_off;
-    const double* src = dscr + ((int64_t)blockIdx.y * 2 + ((j0 / NB) & 1)) * (NB * NB);
-    const int tid = threadIdx.x;
     if (tid < nb) dq[tid] = src[tid + NB * tid];
     if (lin == 0) {
         for (int i = tid; i < nb * nb; i += 256) {
@@ -445,6 +494,7 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] += pr[a] * qc[b];
     }
+    const int nskip = (lin == 0 && look) ? min(NB, k - j1) : 0;     // corner owned by the look-ahead workgroup
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int c = cbase + ty + 16 * b;
@@ -452,28 +502,7 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int r = rbase + tx + 16 * a;
-            if (r < m && r >= c) {
-                const double val = W[r + (int64_t)c * m] - acc[a][b];
-                W[r + (int64_t)c * m] = val;
-                if (lin == 0 && r - j1 < NB && c - j1 < NB) Dn[r - j1][c - j1] = val;
-            }
-        }
-    }
-    // Look-ahead: tile 0 holds the next diagonal block; factor it here, off the critical path of
-    // the other tiles, so that the next panel kernel starts with its row solves at once.
-    if (lin == 0 && j1 < k) {
-        const int nbn = min(NB, k - j1);
-        double* nslot = dscr + ((int64_t)blockIdx.y * 2 + ((j1 / NB) & 1)) * (NB * NB);
-        __syncthreads();
-        if (tid < 64) {
-            double d[NB];
-#pragma unroll
-            for (int c = 0; c < NB; ++c) d[c] = (tid < nbn && c <= tid) ? Dn[tid][c] : 0.0;
-            const bool bad = wave_ldlt_regs<NB>(d, nbn, tid);
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-                if (tid < nbn && c <= tid) nslot[tid + NB * c] = d[c];
-            if (bad && tid == 0) atomicOr(status, 1);
+            if (r < m && r >= c && !(r - j1 < nskip && c - j1 < nskip)) W[r + (int64_t)c * m] -= acc[a][b];
         }
     }
 }
@@ -752,7 +781,7 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                                        d_dscr.p, d_status.p, j0 == 0 ? 1 : 0);
                     const int T = (rem - 1 + ST - 1) / ST;       // trailing tiles (upper bound)
                     if (T > 0) {
-                        const dim3 gu(T * (T + 1) / 2, L.count);
+                        const dim3 gu(T * (T + 1) / 2 + 1, L.count);     // + the look-ahead workgroup
                         hipLaunchKernelGGL(mf_big_update, gu, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p,
                                            d_dscr.p, d_status.p);
                     }
