@@ -82,8 +82,11 @@ __device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NBT], int nb, int lan
             const double lr = aj * inv;
 #pragma unroll
             for (int c = j + 1; c < NBT; ++c) {
-                const double v = readlane_f64(aj, c);     // unscaled entry (c, j)
-                if (c < nb && lane >= c) a[c] -= lr * v;
+                // unscaled entry (c, j).  No lane predicate: lanes above the diagonal (lane < c)
+                // only touch their never-read upper-triangle slots, and rows/columns >= nb hold
+                // zeros, so the update is a plain FMA with an SGPR operand.
+                const double v = readlane_f64(aj, c);
+                a[c] -= lr * v;
             }
             if (lane > j) a[j] = lr;
         }
@@ -427,20 +430,26 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
         if (!look) return;
         const int nbn = min(NB, k - j1);
         double* nslot = dscr + ((int64_t)blockIdx.y * 2 + ((j1 / NB) & 1)) * (NB * NB);
-        if (tid < nb) dq[tid] = src[tid + NB * tid];
-        for (int i = tid; i < NB * NB; i += 256) {
-            const int rr = i % NB, q = i / NB;
+        if (tid < NB) dq[tid] = (tid < nb) ? src[tid + NB * tid] : 0.0;
+        double w0[NB * NB / 256];                // corner entries, loaded while the panel rows arrive
+#pragma unroll
+        for (int t = 0; t < NB * NB / 256; ++t) {
+            const int i = tid + 256 * t, rr = i % NB, c = i / NB;
+            w0[t] = (rr >= c && rr < nbn) ? W[(j1 + rr) + (int64_t)(j1 + c) * m] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < NB * NB / 256; ++t) {
+            const int i = tid + 256 * t, rr = i % NB, q = i / NB;
             Pi[q][rr] = (rr < nbn && q < nb) ? W[(j1 + rr) + (int64_t)(j0 + q) * m] : 0.0;
         }
         __syncthreads();
-        for (int i = tid; i < NB * NB; i += 256) {
-            const int rr = i % NB, c = i / NB;
-            if (rr >= c && rr < nbn) {
-                double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < NB * NB / 256; ++t) {
+            const int i = tid + 256 * t, rr = i % NB, c = i / NB;
+            double acc = 0.0;
 #pragma unroll 8
-                for (int q = 0; q < NB; ++q) acc += Pi[q][rr] * (Pi[q][c] * dq[q < nb ? q : 0]);
-                Dn[rr][c] = W[(j1 + rr) + (int64_t)(j1 + c) * m] - acc;
-            }
+            for (int q = 0; q < NB; ++q) acc += Pi[q][rr] * (Pi[q][c] * dq[q]);
+            Dn[rr][c] = w0[t] - acc;
         }
         __syncthreads();
         if (tid < 64) {
