@@ -20,6 +20,8 @@
 // fixed order on disjoint destination columns: no atomics, bitwise reproducible factors.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -748,11 +750,41 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             i = j;
         }
     }
+    // the wave-per-front solve kernels do not depend on the LDS class: one launch per level
+    level_solves.assign(nlev, {});
+    for (int32_t l = 0; l < nlev; ++l) {
+        MfLaunch S{};
+        for (auto& L : level_launches[l]) {
+            if (!L.cls) { level_solves[l].push_back(L); continue; }
+            if (S.count == 0) S = L;
+            else {
+                S.count += L.count;
+                S.max_m = std::max(S.max_m, L.max_m);
+                S.max_k = std::max(S.max_k, L.max_k);
+            }
+        }
+        if (S.count) level_solves[l].insert(level_solves[l].begin(), S);
+    }
     int32_t max_big = 1;
     for (auto& lev : level_launches)
         for (auto& L : lev)
             if (!L.cls) max_big = std::max(max_big, L.count);
     d_dscr.alloc((size_t)max_big * 2 * NB * NB);
+    if (const char* e = getenv("MGBHIP_DEBUG"); e && atoi(e) >= 2) {
+        fprintf(stderr, "[mgbhip] solver plan: n=%lld fronts=%d levels=%d arena=%.1f MB\n", (long long)plan.n, nf, nlev,
+                plan.arena_doubles * 8e-6);
+        for (int32_t l = 0; l < nlev; ++l)
+            for (auto& L : level_launches[l]) {
+                double sm = 0, sk = 0, fl = 0;
+                for (int32_t q = L.first; q < L.first + L.count; ++q) {
+                    const Front& f = plan.fronts[q];
+                    sm += f.m; sk += f.k;
+                    for (int c = 0; c < f.k; ++c) fl += (double)(f.m - c) * (f.m - c);
+                }
+                fprintf(stderr, "[mgbhip]   level %2d cls %3d count %7d max_m %4d max_k %4d avg_m %6.1f avg_k %6.1f Mflop %8.2f\n",
+                        l, L.cls, L.count, L.max_m, L.max_k, sm / L.count, sk / L.count, fl * 1e-6);
+            }
+    }
     analyzed = true;
     MGB_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
 }
@@ -804,7 +836,7 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
 void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers* timers) {
     MGB_REQUIRE(analyzed, "MfSolver::solve before analyze");
     if (timers) timers->begin("trisolve");
-    for (auto& lev : level_launches)
+    for (auto& lev : level_solves)
         for (auto& L : lev) {
             if (L.count == 0) continue;
             if (L.cls) {
@@ -826,8 +858,8 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
                                    d_arena.p, d_tbig.p, d_tsol.p, d_y.p, d_uvec.p);
             }
         }
-    for (int32_t l = (int32_t)level_launches.size() - 1; l >= 0; --l)
-        for (auto it = level_launches[l].rbegin(); it != level_launches[l].rend(); ++it) {
+    for (int32_t l = (int32_t)level_solves.size() - 1; l >= 0; --l)
+        for (auto it = level_solves[l].rbegin(); it != level_solves[l].rend(); ++it) {
             const MfLaunch& L = *it;
             if (L.count == 0) continue;
             if (L.cls) {

@@ -38,7 +38,8 @@ class MfSolver {
     DevBuf<int32_t> d_front_idx, d_children, d_rel, d_a_src, d_a_dst;
     DevBuf<double> d_arena, d_uvec, d_y, d_tbig, d_tsol, d_dscr;
     DevBuf<int32_t> d_status;
-    std::vector<std::vector<MfLaunch>> level_launches;   // per level, leaves first
+    std::vector<std::vector<MfLaunch>> level_launches;   // per level, leaves first (factorization: one per LDS class)
+    std::vector<std::vector<MfLaunch>> level_solves;     // triangular solves: all LDS-class fronts of a level in one launch
     int32_t lds_cap = 88;           // largest m factored out of LDS
 };
 
