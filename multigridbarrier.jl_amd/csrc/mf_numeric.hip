@@ -34,7 +34,7 @@ namespace {
 
 constexpr int TX = 16;    // row lanes of the 2-D thread maps
 constexpr int NB = 32;    // panel width of the large-front path
-constexpr int CT = 32;    // destination columns per workgroup in the large-front assembly
+constexpr int CT = 8;     // destination columns per workgroup in the large-front assembly (2 per wave)
 constexpr int TR = 256;   // rows per workgroup in the panel solve
 constexpr int ST = 64;    // tile edge of the symmetric update
 
@@ -282,10 +282,10 @@ __global__ __launch_bounds__(256) void mf_big_assemble(const FrontDev* __restric
     const int c1 = min(c0 + CT, m);
     double* W = arena + F.F_off;
     const int tid = threadIdx.x;
-    const int tx = tid % TX, ty = tid / TX;     // 16 x 16
-    for (int c = c0 + ty; c < c1; c += 16) {
+    const int lane = tid & 63, wave = tid >> 6;     // one wave per destination column, lanes on the rows
+    for (int c = c0 + wave; c < c1; c += 4) {
         double* Wc = W + (int64_t)c * m;
-        for (int r = c + tx; r < m; r += TX) Wc[r] = 0.0;
+        for (int r = c + lane; r < m; r += 64) Wc[r] = 0.0;
     }
     __syncthreads();
     {   // A entries are ordered by destination column: binary search the range of [c0, c1)
@@ -311,10 +311,27 @@ __global__ __launch_bounds__(256) void mf_big_assemble(const FrontDev* __restric
         hi = b;
         while (lo < hi) { int mid = (lo + hi) >> 1; if (rl[mid] < c1) lo = mid + 1; else hi = mid; }
         const int je = lo;
-        for (int j = jb + ty; j < je; j += 16) {
+        for (int j = jb + wave; j < je; j += 4) {
             double* Wc = W + (int64_t)rl[j] * m;
             const double* Uc = U + (int64_t)(kc + j) * mc + kc;
-            for (int r = j + tx; r < b; r += TX) Wc[rl[r]] += Uc[r];
+            // the read-modify-write chain rl -> W is latency bound and W may alias U for the
+            // compiler: stage four independent rows per lane so their loads are in flight together
+            for (int r = j + lane; r < b; r += 256) {
+                const int r1 = r + 64, r2 = r + 128, r3 = r + 192;
+                const int i0 = rl[r];
+                const int i1 = r1 < b ? rl[r1] : i0;
+                const int i2 = r2 < b ? rl[r2] : i0;
+                const int i3 = r3 < b ? rl[r3] : i0;
+                const double u0 = Uc[r];
+                const double u1 = r1 < b ? Uc[r1] : 0.0;
+                const double u2 = r2 < b ? Uc[r2] : 0.0;
+                const double u3 = r3 < b ? Uc[r3] : 0.0;
+                const double w0 = Wc[i0], w1 = Wc[i1], w2 = Wc[i2], w3 = Wc[i3];
+                Wc[i0] = w0 + u0;
+                if (r1 < b) Wc[i1] = w1 + u1;
+                if (r2 < b) Wc[i2] = w2 + u2;
+                if (r3 < b) Wc[i3] = w3 + u3;
+            }
         }
         __syncthreads();
     }
