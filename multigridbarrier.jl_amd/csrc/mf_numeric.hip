@@ -697,6 +697,144 @@ __global__ __launch_bounds__(256) void mf_bwd_big_step(const FrontDev* __restric
     }
 }
 
+
+// ---- large-front triangular solves, one workgroup per front -----------------------------------
+// The block steps of a triangular solve are a chain of dependent latencies (diagonal block ->
+// row update -> next diagonal block); the arithmetic is tiny.  One 1024-thread workgroup per
+// front keeps the whole work vector in LDS and turns every kernel boundary of the multi-launch
+// path into a workgroup barrier; fronts of a level run side by side on their own CUs.  L is
+// streamed once (coalesced along rows in the forward sweep).  Used while the vector fits in LDS.
+constexpr int BIG1_THREADS = 1024;
+constexpr int BIG1_MAX_M = 6000;       // work vector + diagonal block within the 64 KB static LDS budget
+
+__global__ __launch_bounds__(BIG1_THREADS) void mf_fwd_big1(const FrontDev* __restrict__ fr, int32_t first,
+                                                            const int32_t* __restrict__ front_idx,
+                                                            const int32_t* __restrict__ children,
+                                                            const int32_t* __restrict__ rel,
+                                                            const double* __restrict__ arena,
+                                                            const double* __restrict__ b, double* __restrict__ y,
+                                                            double* __restrict__ uvec) {
+    extern __shared__ double sh[];
+    const FrontDev F = fr[first + blockIdx.x];
+    const int m = F.m, k = F.k;
+    const int tid = threadIdx.x, nt = BIG1_THREADS;
+    double* tl = sh;                         // [m]
+    double* Dk = sh + ((m + 1) & ~1);        // [NB][NB + 1]
+    const int32_t* idx = front_idx + F.idx_off;
+    const double* Fm = arena + F.F_off;
+    for (int j = tid; j < m; j += nt) tl[j] = (j < k) ? b[idx[j]] : 0.0;
+    __syncthreads();
+    for (int c = 0; c < F.nchild; ++c) {
+        const FrontDev C = fr[children[F.child_off + c]];
+        const int32_t* rl = rel + C.rel_off;
+        const double* uc = uvec + C.u_off;
+        const int bc = C.m - C.k;
+        for (int j = tid; j < bc; j += nt) tl[rl[j]] += uc[j];
+        __syncthreads();
+    }
+    // strictly-lower entry (r, c) of the first diagonal block, one per thread
+    const int dr = tid % NB, dc = tid / NB;
+    double dnext = (dr > dc && dr < k && dc < k) ? Fm[dr + (int64_t)dc * m] : 0.0;
+    for (int j0 = 0; j0 < k; j0 += NB) {
+        const int nb = min(NB, k - j0);
+        Dk[dr * (NB + 1) + dc] = dnext;
+        __syncthreads();
+        {   // prefetch the next diagonal block while this one is used
+            const int jn = j0 + NB;
+            dnext = (dr > dc && jn + dr < k && jn + dc < k) ? Fm[(jn + dr) + (int64_t)(jn + dc) * m] : 0.0;
+        }
+        if (tid < 64) {
+            double v = (tid < nb) ? tl[j0 + tid] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const double tc = readlane_f64(v, c);
+                if (tid > c && tid < NB) v -= Dk[tid * (NB + 1) + c] * tc;      // rows/columns >= nb hold zeros
+            }
+            if (tid < nb) tl[j0 + tid] = v;
+        }
+        __syncthreads();
+        for (int r = j0 + nb + tid; r < m; r += nt) {
+            const double* Lr = Fm + r + (int64_t)j0 * m;
+            double v = tl[r];
+            if (nb == NB) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) v -= Lr[(int64_t)c * m] * tl[j0 + c];
+            } else {
+                for (int c = 0; c < nb; ++c) v -= Lr[(int64_t)c * m] * tl[j0 + c];
+            }
+            tl[r] = v;
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < m; j += nt) {
+        if (j < k) y[idx[j]] = tl[j] / Fm[j + (int64_t)j * m];
+        else uvec[F.u_off + j - k] = tl[j];
+    }
+}
+
+__global__ __launch_bounds__(BIG1_THREADS) void mf_bwd_big1(const FrontDev* __restrict__ fr, int32_t first,
+                                                            const int32_t* __restrict__ front_idx,
+                                                            const double* __restrict__ arena,
+                                                            const double* __restrict__ y, double* __restrict__ x) {
+    extern __shared__ double sh[];
+    const FrontDev F = fr[first + blockIdx.x];
+    const int m = F.m, k = F.k;
+    const int tid = threadIdx.x, nt = BIG1_THREADS;
+    const int lane = tid & 63, wave = tid >> 6;
+    double* tl = sh;                         // [m]: pivots hold the running right-hand side, the rest x(boundary)
+    double* Dk = sh + ((m + 1) & ~1);        // [NB][NB + 1]
+    const int32_t* idx = front_idx + F.idx_off;
+    const double* Fm = arena + F.F_off;
+    for (int j = tid; j < m; j += nt) tl[j] = (j < k) ? y[idx[j]] : x[idx[j]];
+    __syncthreads();
+    // v[q] = y[q] - sum_{r >= k} L[r, q] x[r]: one wave per pivot column
+    for (int q = wave; q < k; q += nt / 64) {
+        const double* Lq = Fm + (int64_t)q * m;
+        double s = 0.0;
+        for (int r = k + lane; r < m; r += 64) s += Lq[r] * tl[r];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) tl[q] -= s;
+    }
+    __syncthreads();
+    const int dr = tid % NB, dc = tid / NB;
+    const int last = ((k - 1) / NB) * NB;
+    double dnext = (dr > dc && last + dr < k) ? Fm[(last + dr) + (int64_t)(last + dc) * m] : 0.0;
+    for (int j0 = last; j0 >= 0; j0 -= NB) {
+        const int nb = min(NB, k - j0);
+        Dk[dr * (NB + 1) + dc] = dnext;
+        __syncthreads();
+        if (j0 >= NB) {
+            const int jn = j0 - NB;          // full block
+            dnext = (dr > dc) ? Fm[(jn + dr) + (int64_t)(jn + dc) * m] : 0.0;
+        }
+        if (tid < 64) {
+            double v = (tid < nb) ? tl[j0 + tid] : 0.0;
+#pragma unroll
+            for (int c = NB - 1; c >= 0; --c) {
+                const double xc = readlane_f64(v, c);
+                if (tid < c) v -= Dk[c * (NB + 1) + tid] * xc;      // rows/columns >= nb hold zeros
+            }
+            if (tid < nb) {
+                tl[j0 + tid] = v;
+                x[idx[j0 + tid]] = v;
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < j0; q += nt) {
+            const double* Lq = Fm + (int64_t)q * m + j0;
+            double v = tl[q];
+            if (nb == NB) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) v -= Lq[c] * tl[j0 + c];
+            } else {
+                for (int c = 0; c < nb; ++c) v -= Lq[c] * tl[j0 + c];
+            }
+            tl[q] = v;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st) {
@@ -861,6 +999,10 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
                 hipLaunchKernelGGL(mf_forward_small, dim3((L.count + 3) / 4), dim3(256), (size_t)4 * ts * sizeof(double),
                                    st, d_fronts.p, L.first, L.count, ts, d_front_idx.p, d_children.p, d_rel.p,
                                    d_arena.p, d_b, d_y.p, d_uvec.p);
+            } else if (L.max_m <= BIG1_MAX_M) {
+                const size_t lds = (size_t)(((L.max_m + 1) & ~1) + NB * (NB + 1)) * sizeof(double);
+                hipLaunchKernelGGL(mf_fwd_big1, dim3(L.count), dim3(BIG1_THREADS), lds, st, d_fronts.p, L.first,
+                                   d_front_idx.p, d_children.p, d_rel.p, d_arena.p, d_b, d_y.p, d_uvec.p);
             } else {
                 const dim3 gi((L.max_m + 255) / 256, L.count);
                 hipLaunchKernelGGL(mf_fwd_big_init, gi, dim3(256), 0, st, d_fronts.p, L.first, d_front_idx.p,
@@ -882,6 +1024,10 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
             if (L.cls) {
                 hipLaunchKernelGGL(mf_backward_small, dim3((L.count + 3) / 4), dim3(256), 0, st, d_fronts.p, L.first,
                                    L.count, d_front_idx.p, d_arena.p, d_y.p, d_x);
+            } else if (L.max_m <= BIG1_MAX_M) {
+                const size_t lds = (size_t)(((L.max_m + 1) & ~1) + NB * (NB + 1)) * sizeof(double);
+                hipLaunchKernelGGL(mf_bwd_big1, dim3(L.count), dim3(BIG1_THREADS), lds, st, d_fronts.p, L.first,
+                                   d_front_idx.p, d_arena.p, d_y.p, d_x);
             } else {
                 const dim3 gi((L.max_k + 3) / 4, L.count);
                 hipLaunchKernelGGL(mf_bwd_big_init, gi, dim3(256), 0, st, d_fronts.p, L.first, d_front_idx.p,
