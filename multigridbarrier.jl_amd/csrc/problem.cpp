@@ -286,33 +286,86 @@ void mgbhip_problem::ensure_plan(int level) {
             ecol_ptr[e * nu + a + 1] = (int32_t)ecols.size();
             MGB_REQUIRE(ecols.size() < (size_t)INT32_MAX, "assembly plan exceeds 32-bit indexing");
         }
-    // 2. output pattern: union over elements of (all columns of e) x (all columns of e)
-    const int64_t m = L.m;
-    std::vector<int32_t> cnt(m + 1, 0);
-    for (int64_t e = 0; e < NE; ++e)
-        for (int32_t q = ecol_ptr[e * nu]; q < ecol_ptr[(e + 1) * nu]; ++q) cnt[ecols[q] + 1]++;
-    for (int64_t j = 0; j < m; ++j) cnt[j + 1] += cnt[j];
-    std::vector<int32_t> c2e(cnt[m]);
-    {
-        std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
-        for (int64_t e = 0; e < NE; ++e)
-            for (int32_t q = ecol_ptr[e * nu]; q < ecol_ptr[(e + 1) * nu]; ++q) c2e[fill[ecols[q]]++] = (int32_t)e;
+    // Blocks (a, b) whose D rows are all identity operators are diagonal per element
+    // (Hel_ab[i, j] = sum_r delta_ri Y_r delta_rj): on selection levels their off-diagonal slots
+    // are structural zeros, exactly as in the reference's sparse products, and stay out of the
+    // pattern.  (With default_D this decouples the broken slack unknowns of an element.)
+    bool state_id[MGBHIP_MAX_NU];
+    for (int a = 0; a < nu; ++a) {
+        state_id[a] = true;
+        for (int k = 0; k < nD; ++k)
+            if (D_state[k] == a && !store->identity[D_op[k]]) state_id[a] = false;
     }
+    auto structural = [&](int a, int i, int b, int j) { return !(selection && state_id[a] && state_id[b] && i != j); };
+    auto colof = [&](int a, int64_t e, int r) -> int32_t {
+        const int64_t row = (int64_t)a * nn + e * pp + r;
+        return L.hRptr[row + 1] > L.hRptr[row] ? L.hRcol[L.hRptr[row]] : -1;
+    };
+    // 2. output pattern
+    const int64_t m = L.m;
     L.hHptr.assign(m + 1, 0);
     L.hHcol.clear();
-    std::vector<int32_t> rowbuf;
-    for (int64_t i = 0; i < m; ++i) {
-        rowbuf.clear();
-        for (int32_t t = cnt[i]; t < cnt[i + 1]; ++t) {
-            const int64_t e = c2e[t];
-            rowbuf.insert(rowbuf.end(), ecols.begin() + ecol_ptr[e * nu], ecols.begin() + ecol_ptr[(e + 1) * nu]);
+    if (selection) {
+        // (row, col) pairs of every structural element contribution, bucketed by row
+        std::vector<int32_t> rc(m + 1, 0);
+        auto each_pair = [&](auto&& emit) {
+            for (int64_t e = 0; e < NE; ++e)
+                for (int a = 0; a < nu; ++a)
+                    for (int i = 0; i < pp; ++i) {
+                        const int32_t ci = colof(a, e, i);
+                        if (ci < 0) continue;
+                        for (int b = 0; b < nu; ++b)
+                            for (int j = 0; j < pp; ++j) {
+                                if (!structural(a, i, b, j)) continue;
+                                const int32_t cj = colof(b, e, j);
+                                if (cj >= 0) emit(ci, cj);
+                            }
+                    }
+        };
+        each_pair([&](int32_t ci, int32_t) { rc[ci + 1]++; });
+        std::vector<int64_t> off(m + 1, 0);
+        for (int64_t i = 0; i < m; ++i) off[i + 1] = off[i] + rc[i + 1];
+        std::vector<int32_t> cols((size_t)off[m]);
+        {
+            std::vector<int64_t> fill(off.begin(), off.end() - 1);
+            each_pair([&](int32_t ci, int32_t cj) { cols[(size_t)fill[ci]++] = cj; });
         }
-        if (rowbuf.empty()) rowbuf.push_back((int32_t)i);   // unknown untouched by any element: keep a diagonal slot
-        std::sort(rowbuf.begin(), rowbuf.end());
-        rowbuf.erase(std::unique(rowbuf.begin(), rowbuf.end()), rowbuf.end());
-        L.hHcol.insert(L.hHcol.end(), rowbuf.begin(), rowbuf.end());
-        MGB_REQUIRE(L.hHcol.size() < (size_t)INT32_MAX, "Hessian pattern exceeds 32-bit indexing");
-        L.hHptr[i + 1] = (int32_t)L.hHcol.size();
+        for (int64_t i = 0; i < m; ++i) {
+            int32_t* lo = cols.data() + off[i];
+            int32_t* hi = cols.data() + off[i + 1];
+            std::sort(lo, hi);
+            hi = std::unique(lo, hi);
+            if (lo == hi) L.hHcol.push_back((int32_t)i);     // unknown untouched by any element: keep a diagonal slot
+            else L.hHcol.insert(L.hHcol.end(), lo, hi);
+            MGB_REQUIRE(L.hHcol.size() < (size_t)INT32_MAX, "Hessian pattern exceeds 32-bit indexing");
+            L.hHptr[i + 1] = (int32_t)L.hHcol.size();
+        }
+    } else {
+        // union over elements of (all columns of e) x (all columns of e)
+        std::vector<int32_t> cnt(m + 1, 0);
+        for (int64_t e = 0; e < NE; ++e)
+            for (int32_t q = ecol_ptr[e * nu]; q < ecol_ptr[(e + 1) * nu]; ++q) cnt[ecols[q] + 1]++;
+        for (int64_t j = 0; j < m; ++j) cnt[j + 1] += cnt[j];
+        std::vector<int32_t> c2e(cnt[m]);
+        {
+            std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
+            for (int64_t e = 0; e < NE; ++e)
+                for (int32_t q = ecol_ptr[e * nu]; q < ecol_ptr[(e + 1) * nu]; ++q) c2e[fill[ecols[q]]++] = (int32_t)e;
+        }
+        std::vector<int32_t> rowbuf;
+        for (int64_t i = 0; i < m; ++i) {
+            rowbuf.clear();
+            for (int32_t t = cnt[i]; t < cnt[i + 1]; ++t) {
+                const int64_t e = c2e[t];
+                rowbuf.insert(rowbuf.end(), ecols.begin() + ecol_ptr[e * nu], ecols.begin() + ecol_ptr[(e + 1) * nu]);
+            }
+            if (rowbuf.empty()) rowbuf.push_back((int32_t)i);   // unknown untouched by any element: keep a diagonal slot
+            std::sort(rowbuf.begin(), rowbuf.end());
+            rowbuf.erase(std::unique(rowbuf.begin(), rowbuf.end()), rowbuf.end());
+            L.hHcol.insert(L.hHcol.end(), rowbuf.begin(), rowbuf.end());
+            MGB_REQUIRE(L.hHcol.size() < (size_t)INT32_MAX, "Hessian pattern exceeds 32-bit indexing");
+            L.hHptr[i + 1] = (int32_t)L.hHcol.size();
+        }
     }
     L.nnz = (int64_t)L.hHcol.size();
     L.Hptr.upload(L.hHptr, st);
@@ -338,10 +391,6 @@ void mgbhip_problem::ensure_plan(int level) {
         MGB_REQUIRE(eoff[NE] < (int64_t)INT32_MAX, "projected slab exceeds 32-bit indexing");
         L.slab_doubles = eoff[NE];
     }
-    auto colof = [&](int a, int64_t e, int r) -> int32_t {
-        const int64_t row = (int64_t)a * nn + e * pp + r;
-        return L.hRptr[row + 1] > L.hRptr[row] ? L.hRcol[L.hRptr[row]] : -1;
-    };
     auto for_each = [&](auto&& emit) {
         if (selection) {
             for (int64_t e = 0; e < NE; ++e)
@@ -351,6 +400,7 @@ void mgbhip_problem::ensure_plan(int level) {
                         if (ci < 0) continue;
                         for (int b = 0; b < nu; ++b)
                             for (int j = 0; j < pp; ++j) {
+                                if (!structural(a, i, b, j)) continue;
                                 const int32_t cj = colof(b, e, j);
                                 if (cj < 0) continue;
                                 int64_t src;   // slab index of Hel_ab[i, j] (upper block triangle stored)
