@@ -187,8 +187,9 @@ __global__ __launch_bounds__(256) void elem_kernel(const ElemParams P, const int
             for (int a = 0; a < nu; ++a)
                 for (int b = a; b < nu; ++b) {
                     const int blk = a * nu - (a * (a - 1)) / 2 + (b - a);
-                    double* out = P.out_hel + (((int64_t)blk * P.N + e) * p + j) * (int64_t)p;
-                    for (int i = 0; i < p; ++i) {
+                    const bool dblk = (P.diag_mask >> blk) & 1;
+                    double* out = P.out_hel + P.blk_off[blk] + (dblk ? (e * p + j) - j : (e * p + j) * (int64_t)p);
+                    for (int i = dblk ? j : 0; i < (dblk ? j + 1 : p); ++i) {
                         double val = 0.0;
 #pragma unroll
                         for (int k = 0; k < NY; ++k) {
@@ -324,7 +325,8 @@ __global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
         for (int b = a; b < nu; ++b, ++blk) {
             // lane j owns column j of the block: P contiguous doubles of the block-major slab; a wave
             // covers 64/G whole blocks, so every cache line is completed within the wave's stores
-            double* dst = Pm.out_hel + (((int64_t)blk * Pm.N + e) * P + j) * (int64_t)P;
+            const bool dblk = (Pm.diag_mask >> blk) & 1;      // diagonal block, stored compactly
+            double* dst = Pm.out_hel + Pm.blk_off[blk] + (dblk ? (e * P + j) : (e * P + j) * (int64_t)P);
             bool b_all_id = true;
 #pragma unroll
             for (int k2 = 0; k2 < NY; ++k2)
@@ -346,16 +348,24 @@ __global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
                     }
                     Cd[k] = acc;
                 }
-#pragma unroll
-                for (int i = 0; i < P; ++i) {
+                if (dblk) {          // state a carries identity operators only as well
                     double val = 0.0;
 #pragma unroll
-                    for (int k = 0; k < NY; ++k) {
-                        if (DST(k) != a || !((ymask >> k) & 1)) continue;
-                        if (DSG(k) < 0) val += (i == j) ? Cd[k] : 0.0;
-                        else val += OP(k, j, i) * Cd[k];
+                    for (int k = 0; k < NY; ++k)
+                        if (DST(k) == a && ((ymask >> k) & 1)) val += Cd[k];
+                    dst[0] = val;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < P; ++i) {
+                        double val = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NY; ++k) {
+                            if (DST(k) != a || !((ymask >> k) & 1)) continue;
+                            if (DSG(k) < 0) val += (i == j) ? Cd[k] : 0.0;
+                            else val += OP(k, j, i) * Cd[k];
+                        }
+                        dst[i] = val;
                     }
-                    dst[i] = val;
                 }
             } else if (active) {
                 double C[NY][P];

@@ -27,6 +27,8 @@ struct ElemParams {
     double* out_hel;                         // f2: element Hessian blocks
     double* out_F;                           // node maps
     double* out_Dz;
+    int32_t diag_mask;                       // bit blk set: element block blk is diagonal and stored compactly (p per element)
+    int64_t blk_off[MGBHIP_MAX_NU * (MGBHIP_MAX_NU + 1) / 2];   // slab offset of every element block
     double* dn_Dz;                           // dense path (p > 64, N = 1): n x nD workspace for D*z
     double* dn_Y;                            // dense path: n x nD (f1) / n x nD(nD+1)/2 (f2) node weights
 };
@@ -35,6 +37,16 @@ struct ElemParams {
 // row-major order of the upper block triangle, each p x p column-major.
 inline int hel_blocks(int nu) { return nu * (nu + 1) / 2; }
 inline int hel_block_index(int a, int b, int nu) { return a * nu - a * (a - 1) / 2 + (b - a); }
+// Offsets of the blocks in the slab: full blocks hold p*p doubles per element, blocks flagged in
+// diag_mask (both states carry identity operators only) hold their p diagonal entries.
+inline int64_t hel_layout(int nu, int64_t N, int p, int diag_mask, int64_t* off) {
+    int64_t total = 0;
+    for (int blk = 0; blk < hel_blocks(nu); ++blk) {
+        off[blk] = total;
+        total += ((diag_mask >> blk) & 1) ? N * p : N * (int64_t)p * p;
+    }
+    return total;
+}
 
 int elem_group(int p);                                   // lanes per element (power of two >= p)
 int64_t elem_grid(int p, int64_t N);                     // workgroups

@@ -127,6 +127,18 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
         P->D_stage[k] = slot_of_op[o];
     }
     for (int k = d->nD; k < MGBHIP_MAX_ND; ++k) { P->D_state[k] = -1; P->D_op[k] = 0; P->D_stage[k] = -1; }
+    {
+        bool sid[MGBHIP_MAX_NU];
+        for (int a = 0; a < d->nu; ++a) {
+            sid[a] = true;
+            for (int k = 0; k < d->nD; ++k)
+                if (d->D_state[k] == a && !P->store->identity[d->D_op[k]]) sid[a] = false;
+        }
+        P->diag_mask_sel = 0;
+        for (int a = 0; a < d->nu; ++a)
+            for (int b = a; b < d->nu; ++b)
+                if (sid[a] && sid[b]) P->diag_mask_sel |= 1 << hel_block_index(a, b, d->nu);
+    }
 
     // cone
     const mgbhip_cone& C = d->cone;
@@ -391,6 +403,8 @@ void mgbhip_problem::ensure_plan(int level) {
         MGB_REQUIRE(eoff[NE] < (int64_t)INT32_MAX, "projected slab exceeds 32-bit indexing");
         L.slab_doubles = eoff[NE];
     }
+    int64_t sel_off[MGBHIP_MAX_NU * (MGBHIP_MAX_NU + 1) / 2];
+    hel_layout(nu, NE, pp, diag_mask_sel, sel_off);
     auto for_each = [&](auto&& emit) {
         if (selection) {
             for (int64_t e = 0; e < NE; ++e)
@@ -404,8 +418,10 @@ void mgbhip_problem::ensure_plan(int level) {
                                 const int32_t cj = colof(b, e, j);
                                 if (cj < 0) continue;
                                 int64_t src;   // slab index of Hel_ab[i, j] (upper block triangle stored)
-                                if (a <= b) src = (((int64_t)hel_block_index(a, b, nu) * NE + e) * pp + j) * (int64_t)pp + i;
-                                else src = (((int64_t)hel_block_index(b, a, nu) * NE + e) * pp + i) * (int64_t)pp + j;
+                                const int blk = a <= b ? hel_block_index(a, b, nu) : hel_block_index(b, a, nu);
+                                if ((diag_mask_sel >> blk) & 1) src = sel_off[blk] + e * pp + i;            // i == j here
+                                else if (a <= b) src = sel_off[blk] + (e * pp + j) * (int64_t)pp + i;
+                                else src = sel_off[blk] + (e * pp + i) * (int64_t)pp + j;
                                 emit(find(ci, cj), src);
                             }
                     }
@@ -553,6 +569,8 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
         StageScope sc(ctx->timers, "f2");
         ElemParams E = base_params(level, d_s, d_zz, d_cc);
         E_ymask = E.ymask;
+        E.diag_mask = (L.selection && !dense) ? diag_mask_sel : 0;
+        hel_layout(nu, N, p, E.diag_mask, E.blk_off);
         launch_elem(E, MODE_F2, st);
     }
     {

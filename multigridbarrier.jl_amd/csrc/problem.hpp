@@ -60,6 +60,7 @@ struct mgbhip_problem {
     mgbhip_ctx* ctx = nullptr;
     int32_t p = 0, nu = 0, nD = 0;
     int64_t N = 0, n = 0;
+    int32_t diag_mask_sel = 0;             // element blocks that are diagonal (identity-only states), compact on selection levels
     bool dense = false;                    // one dense spectral element (p > 64): dense.hip path
     std::shared_ptr<mgbhip::OpStore> store;
     int32_t D_state[MGBHIP_MAX_ND], D_op[MGBHIP_MAX_ND], D_stage[MGBHIP_MAX_ND];
