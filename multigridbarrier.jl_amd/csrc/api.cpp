@@ -126,6 +126,7 @@ static void stage_inputs(mgbhip_problem* P, int32_t level, const double* s, cons
     P->d_x.upload(s, (size_t)P->levels[level].m, st);
     P->d_c.upload(c, (size_t)P->n * P->nD, st);
     P->d_z0.upload(z0, (size_t)P->nu * P->n, st);
+    P->touch();
 }
 
 int mgbhip_f0(mgbhip_problem* P, int32_t level, const double* s, const double* c, const double* z0, double* value) {

@@ -99,6 +99,7 @@ bool linesearch_backtracking(NewtonCtx& C, const mgbhip_options& opt, double y, 
     while (s > 0.0) {
         P->d_flag.zero(st, 1);
         launch_step(P->d_x.p, P->d_nv.p, s, P->d_xn.p, C.m, P->d_flag.p, st);
+        P->touch();
         double yn, gn;
         if (trial_values(C, yn, gn)) {
             int32_t moved = 0;
@@ -123,6 +124,7 @@ bool linesearch_illinois(NewtonCtx& C, const mgbhip_options& opt, double inc, do
     auto phi = [&](double sigma) -> double {
         P->d_flag.zero(st, 1);
         launch_step(P->d_x.p, P->d_nv.p, sigma, P->d_xn.p, C.m, P->d_flag.p, st);
+        P->touch();
         const double f = C.F0(P->d_xn.p);
         if (!std::isfinite(f)) throw Reject();
         C.F1(P->d_xn.p, P->d_gn.p);
@@ -149,6 +151,7 @@ bool linesearch_illinois(NewtonCtx& C, const mgbhip_options& opt, double inc, do
             if (!done) throw Reject();
             P->d_flag.zero(st, 1);
             launch_step(P->d_x.p, P->d_nv.p, root, P->d_xn.p, C.m, P->d_flag.p, st);
+        P->touch();
             double yn, gn;
             if (!trial_values(C, yn, gn)) throw Reject();
             ynext = yn;
@@ -166,6 +169,7 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
     hipStream_t st = P->stream();
     NewtonResult R;
     P->d_x.zero(st, (size_t)C.m);                        // s0 = zeros (src/mgb.jl:45)
+    P->touch();                                          // new level / new fine snapshot: drop the cached z0 + R*s
     double y = C.F0(P->d_x.p);
     if (!std::isfinite(y)) throw InvalidArgument("newton: initial objective value is not finite");
     double ymin = y;
@@ -413,6 +417,7 @@ int matched_t_run(mgbhip_problem* P, const double* z, const double* c, double t_
     P->d_c0.upload(c, cn, st);
     P->d_c.zero(st, cn);
     P->d_x.zero(st, (size_t)m);
+    P->touch();
     *t_out = t_default;
     // gphi = f1(c = 0); gc = f1(c) - gphi; H = f2
     P->eval_f1(lev, P->d_x.p, P->d_z0.p, P->d_c.p, P->d_g.p);          // gphi -> d_g

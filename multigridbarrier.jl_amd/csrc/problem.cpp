@@ -509,12 +509,15 @@ ElemParams mgbhip_problem::base_params(int level, const double* d_s, const doubl
     E.z0 = d_zz;
     if (level >= 0 && d_s != nullptr) {
         const Level& L = levels[level];
-        if (L.R_long) {      // dense prolongation rows: wave per row
+        if (zf_stamp == zstamp && zf_level == level && zf_s == d_s && zf_z == d_zz) {
+            // same evaluation point as the previous call: d_zfull is still valid
+        } else if (L.R_long) {      // dense prolongation rows: wave per row
             MGB_HIP_CHECK(hipMemcpyAsync(d_zfull.p, d_zz, sizeof(double) * (size_t)L.rows, hipMemcpyDeviceToDevice, stream()));
             launch_csr_matvec(L.rows, L.Rptr.p, L.Rcol.p, L.Rval.p, d_s, d_zfull.p, true, true, stream());
         } else {
             launch_prolong(L.rows, L.Rptr.p, L.Rcol.p, L.Rval.p, d_s, d_zz, d_zfull.p, stream());
         }
+        zf_stamp = zstamp; zf_level = level; zf_s = d_s; zf_z = d_zz;
         E.z0 = d_zfull.p;
     }
     E.bw = has_bw ? bw.p : nullptr;

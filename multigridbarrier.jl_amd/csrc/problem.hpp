@@ -76,6 +76,14 @@ struct mgbhip_problem {
     mgbhip::DevBuf<double> d_x, d_g, d_nv, d_xn, d_gn, d_tmp, d_c0;
     mgbhip::DevBuf<int32_t> d_flag;
     mgbhip::Counters cnt;
+    // z0 + R*s is cached in d_zfull across the f0/f1/f2 calls at one point: the key is the
+    // (level, s, z) pointers plus a stamp every writer of those vectors bumps (touch()).
+    int64_t zstamp = 0;
+    mutable int64_t zf_stamp = -1;
+    mutable int zf_level = -1;
+    mutable const double* zf_s = nullptr;
+    mutable const double* zf_z = nullptr;
+    void touch() { ++zstamp; }
 
     mgbhip::ElemParams base_params(int level, const double* d_s, const double* d_zz, const double* d_cc) const;
     hipStream_t stream() const { return ctx->stream; }
