@@ -37,6 +37,7 @@ constexpr int NB = 32;    // panel width of the large-front path
 constexpr int CT = 8;     // destination columns per workgroup in the large-front assembly (2 per wave)
 constexpr int TR = 256;   // rows per workgroup in the panel solve
 constexpr int ST = 64;    // tile edge of the symmetric update
+constexpr int CHILD_CHUNK = 64;   // child descriptors staged in LDS at a time
 
 // ------------------------------------------------------------------------------------------------
 // small fronts
@@ -104,7 +105,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                                 const int32_t* __restrict__ children, const int32_t* __restrict__ rel,
                                 const int32_t* __restrict__ a_src, const int32_t* __restrict__ a_dst,
                                 const double* __restrict__ Hval, double* __restrict__ arena,
-                                int32_t* __restrict__ status) {
+                                int32_t* __restrict__ status, int exp_mask) {
     extern __shared__ double W[];
     const FrontDev F = fr[first + blockIdx.x];
     double* Fg = arena + F.F_off;
@@ -117,17 +118,73 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     __syncthreads();
     for (int t = tid; t < F.a_cnt; t += nt) W[a_dst[F.a_off + t]] = Hval[a_src[F.a_off + t]];
     __syncthreads();
-    for (int c = 0; c < F.nchild; ++c) {
-        const FrontDev C = fr[children[F.child_off + c]];
-        const double* U = arena + C.F_off;
-        const int mc = C.m, kc = C.k, b = mc - kc;
-        const int32_t* rl = rel + C.rel_off;
-        for (int j = ty; j < b; j += TYn) {
-            const int dcol = rl[j] * m;
-            const double* Uc = U + (int64_t)(kc + j) * mc + kc;
-            for (int r = j + tx; r < b; r += TX) W[rl[r] + dcol] += Uc[r];
+    // Extend-add of the children.  The additions of different children may hit the same slot, so
+    // children stay ordered (deterministic sums) with a barrier between them -- but their global
+    // loads do not have to: the child descriptors are fetched once into LDS, and the entries of
+    // four children at a time are staged in registers before the first of them is applied, so a
+    // front with many small children (static-condensation leaves under an element patch) pays one
+    // memory latency per four children instead of three dependent ones per child.
+    __shared__ int64_t cU[CHILD_CHUNK];        // arena offset of the child's update block (kc, kc)
+    __shared__ int64_t cR[CHILD_CHUNK];        // rel offset
+    __shared__ int32_t cM[CHILD_CHUNK], cB[CHILD_CHUNK];
+    for (int cbase = 0; cbase < ((exp_mask & 1) ? 0 : F.nchild); cbase += CHILD_CHUNK) {
+        const int nc = min(CHILD_CHUNK, F.nchild - cbase);
+        __syncthreads();
+        if (tid < nc) {
+            const FrontDev C = fr[children[F.child_off + cbase + tid]];
+            cU[tid] = C.F_off + (int64_t)C.k * C.m + C.k;
+            cR[tid] = C.rel_off;
+            cM[tid] = C.m;
+            cB[tid] = C.m - C.k;
         }
         __syncthreads();
+        for (int c0 = 0; c0 < nc; c0 += 4) {
+            int dst[4];
+            double val[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                dst[u] = -1;
+                val[u] = 0.0;
+                const int c = c0 + u;
+                if (c < nc) {
+                    const int b = cB[c];
+                    if (b * b <= nt && tid < b * b) {
+                        const int j = tid / b, r = tid - j * b;
+                        if (r >= j) {
+                            const int32_t* rl = rel + cR[c];
+                            dst[u] = rl[r] + rl[j] * m;
+                            val[u] = arena[cU[c] + (int64_t)j * cM[c] + r];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u;
+                if (c >= nc) break;
+                if (dst[u] >= 0) W[dst[u]] += val[u];
+                const int b = cB[c];
+                if (b * b > nt) {               // larger child: 2-D sweep, two rows per lane in flight
+                    const int32_t* rl = rel + cR[c];
+                    const double* U = arena + cU[c];
+                    const int mc = cM[c];
+                    for (int j = ty; j < b; j += TYn) {
+                        const int dcol = rl[j] * m;
+                        const double* Uc = U + (int64_t)j * mc;
+                        for (int r = j + tx; r < b; r += 2 * TX) {
+                            const int r1 = r + TX;
+                            const int i0 = rl[r];
+                            const int i1 = r1 < b ? rl[r1] : i0;
+                            const double u0 = Uc[r];
+                            const double u1 = r1 < b ? Uc[r1] : 0.0;
+                            W[i0 + dcol] += u0;
+                            if (r1 < b) W[i1 + dcol] += u1;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
     }
     bool bad = false;
     for (int j0 = 0; j0 < k; j0 += NBT) {
@@ -205,12 +262,45 @@ __global__ __launch_bounds__(256) void mf_forward_small(const FrontDev* __restri
     const double* Fm = arena + F.F_off;
     for (int j = lane; j < m; j += 64) t[j] = (j < k) ? b[idx[j]] : 0.0;
     wave_sync();
-    for (int c = 0; c < F.nchild; ++c) {
-        const FrontDev C = fr[children[F.child_off + c]];
-        const int32_t* rl = rel + C.rel_off;
-        const double* uc = uvec + C.u_off;
-        for (int j = lane; j < C.m - C.k; j += 64) t[rl[j]] += uc[j];
-        wave_sync();
+    // children's update vectors: descriptors of up to 64 children are fetched by the lanes in
+    // parallel and broadcast from registers; the loads of four children are in flight together,
+    // the additions stay in child order (deterministic sums)
+    for (int cbase = 0; cbase < F.nchild; cbase += 64) {
+        const int nc = min(64, F.nchild - cbase);
+        int64_t my_u = 0, my_r = 0;
+        int my_b = 0;
+        if (lane < nc) {
+            const FrontDev C = fr[children[F.child_off + cbase + lane]];
+            my_u = C.u_off;
+            my_r = C.rel_off;
+            my_b = C.m - C.k;
+        }
+        for (int c0 = 0; c0 < nc; c0 += 4) {
+            int dst[4];
+            double val[4];
+            int bb[4];
+            int64_t ru[4], rr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = min(c0 + u, nc - 1);
+                bb[u] = (c0 + u < nc) ? __shfl(my_b, c, 64) : 0;
+                ru[u] = __shfl(my_u, c, 64);
+                rr[u] = __shfl(my_r, c, 64);
+                dst[u] = -1;
+                val[u] = 0.0;
+                if (lane < bb[u]) {
+                    dst[u] = rel[rr[u] + lane];
+                    val[u] = uvec[ru[u] + lane];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c0 + u >= nc) break;
+                if (dst[u] >= 0) t[dst[u]] += val[u];
+                for (int j = lane + 64; j < bb[u]; j += 64) t[rel[rr[u] + j]] += uvec[ru[u] + j];
+                wave_sync();
+            }
+        }
     }
     const int r1 = lane + 64;
     double t0 = (lane < m) ? t[lane] : 0.0;
@@ -954,18 +1044,19 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
             if (L.count == 0) continue;
             if (L.cls) {
                 size_t lds = (size_t)L.cls * L.cls * sizeof(double);
+                static const int exp_mask = [] { const char* e = getenv("MGBHIP_EXP"); return e ? atoi(e) : 0; }();
                 static const int nbt_mid = [] { const char* e = getenv("MGBHIP_NBT"); return e ? atoi(e) : 8; }();
                 const int threads = L.cls <= 16 ? 64 : (L.cls <= 32 ? 128 : 256);
                 const int nbt = L.cls <= 16 ? 8 : nbt_mid;
                 if (nbt <= 8)
                     hipLaunchKernelGGL(mf_factor_small<8>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p, exp_mask);
                 else if (nbt <= 16)
                     hipLaunchKernelGGL(mf_factor_small<16>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p, exp_mask);
                 else
                     hipLaunchKernelGGL(mf_factor_small<32>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p, exp_mask);
             } else {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
                 hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,
