@@ -41,7 +41,7 @@ extern "C" {
 
 #define MGBHIP_MAX_PIECES 4
 #define MGBHIP_MAX_IDX 4
-#define MGBHIP_MAX_ND 8
+#define MGBHIP_MAX_ND 10   /* 3-D parabolic phase I: (dim + 3) + 1 + 3 rows */
 #define MGBHIP_MAX_NU 4
 #define MGBHIP_MAX_OPS 8
 

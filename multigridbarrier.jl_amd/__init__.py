@@ -15,6 +15,7 @@ from .tensorfem import fem1d, fem2d, fem3d, TensorFEM, tensor_dofmap
 from .spectral import spectral1d, spectral2d, SPECTRAL1D, SPECTRAL2D
 from .amg_prolongators import amg_ruge_stuben
 from .convex import Convex, Piece, convex_Euclidian_power, convex_linear, convex_piecewise, intersect
+from .parabolic import parabolic_solve, ParabolicSOL
 from .problem import (MGBProblem, assemble, amg, subdivide, find_boundary, default_f, default_g,
                       default_D, default_idx)
 

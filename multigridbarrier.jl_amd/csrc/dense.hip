@@ -345,7 +345,7 @@ void launch_dense_weight(int NY, int klo, int khi, int64_t n, int64_t m, int64_t
     switch (NY) {
 #define MGB_CASE(X) \
     case X: hipLaunchKernelGGL((dense_weight_kernel<X>), grid, blk, 0, st, klo, khi, n, ld, DR, Yh, W); break;
-        MGB_CASE(1) MGB_CASE(2) MGB_CASE(3) MGB_CASE(4) MGB_CASE(5) MGB_CASE(6) MGB_CASE(7) MGB_CASE(8)
+        MGB_CASE(1) MGB_CASE(2) MGB_CASE(3) MGB_CASE(4) MGB_CASE(5) MGB_CASE(6) MGB_CASE(7) MGB_CASE(8) MGB_CASE(9) MGB_CASE(10)
 #undef MGB_CASE
         default: throw InvalidArgument("dense_weight: nD out of range");
     }
@@ -365,7 +365,7 @@ void launch_dense_eval(const ElemParams& P, int mode, hipStream_t st) {
     }
     switch (P.nD) {
 #define MGB_CASE(X) case X: launch_node_ny<X>(P, mode, st); break;
-        MGB_CASE(1) MGB_CASE(2) MGB_CASE(3) MGB_CASE(4) MGB_CASE(5) MGB_CASE(6) MGB_CASE(7) MGB_CASE(8)
+        MGB_CASE(1) MGB_CASE(2) MGB_CASE(3) MGB_CASE(4) MGB_CASE(5) MGB_CASE(6) MGB_CASE(7) MGB_CASE(8) MGB_CASE(9) MGB_CASE(10)
 #undef MGB_CASE
         default: throw InvalidArgument("launch_dense_eval: nD out of range");
     }

@@ -724,6 +724,7 @@ void launch_elem(const ElemParams& P, int mode, hipStream_t st) {
     std::call_once(once, [] {
         set_lds_attr<1>(); set_lds_attr<2>(); set_lds_attr<3>(); set_lds_attr<4>();
         set_lds_attr<5>(); set_lds_attr<6>(); set_lds_attr<7>(); set_lds_attr<8>();
+        set_lds_attr<9>(); set_lds_attr<10>();
     });
     const int G = elem_group(P.p);
     int lgG = 0;
@@ -740,6 +741,8 @@ void launch_elem(const ElemParams& P, int mode, hipStream_t st) {
         case 6: launch_elem_ny<6>(P, mode, lgG, grid, lds, st); break;
         case 7: launch_elem_ny<7>(P, mode, lgG, grid, lds, st); break;
         case 8: launch_elem_ny<8>(P, mode, lgG, grid, lds, st); break;
+        case 9: launch_elem_ny<9>(P, mode, lgG, grid, lds, st); break;
+        case 10: launch_elem_ny<10>(P, mode, lgG, grid, lds, st); break;
     }
     MGB_HIP_CHECK(hipGetLastError());
 }

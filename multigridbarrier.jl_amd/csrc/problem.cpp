@@ -116,8 +116,11 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
         if (P->store->identity[o]) { P->D_stage[k] = -1; continue; }
         if (slot_of_op[o] < 0) {
             // stage through LDS while the operator tiles of one workgroup stay under 64 KB
+            // ... and the whole f2 working set (operators + broken values + nD(nD+1)/2 node weights
+            // per lane) fits the 160 KB of a CU
             size_t bytes = (size_t)(P->nstage + 1) * EPB * P->p * P->p * sizeof(double);
-            if (!P->dense && bytes <= 64 * 1024) {
+            const size_t f2_total = bytes + 256 * sizeof(double) * (size_t)(d->nu + d->nD * (d->nD + 1) / 2);
+            if (!P->dense && bytes <= 64 * 1024 && f2_total <= 150 * 1024) {
                 slot_of_op[o] = P->nstage;
                 P->stage_ptr[P->nstage++] = P->store->ops[o].p;
             } else {

@@ -23,7 +23,7 @@ from .convex import KIND_EP, KIND_LINEAR, Convex
 from .multigrid import AMG
 from .problem import MGBProblem
 
-MAX_PIECES, MAX_IDX, MAX_ND, MAX_NU, MAX_OPS = 4, 4, 8, 4, 8
+MAX_PIECES, MAX_IDX, MAX_ND, MAX_NU, MAX_OPS = 4, 4, 10, 4, 8
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_SPD, ERR_NONFINITE, ERR_CONVERGENCE = range(6)
 
 

@@ -23,7 +23,35 @@ def _literals(path):
     return out
 
 
+def _parabolic_literals(path):
+    """`z = [a b c; d e f;;; ...]` 3-D literals followed by a `parabolic_solve(...)` call
+    (test/runtests.jl:35-52): rows = nodes, columns = (u, s1, s2), slices = time stamps."""
+    txt = open(path).read()
+    out = []
+    for m in re.finditer(r"z\s*=\s*\[([^\]]*;;;[^\]]*)\]\s*\n\s*sol\s*=\s*parabolic_solve\(([^\n]*)\)\n", txt):
+        slices = []
+        for sl in m.group(1).split(";;;"):
+            rows = [[float(v) for v in r.split()] for r in sl.split(";") if r.strip()]
+            slices.append(rows)
+        line = txt[: m.start()].count("\n") + 1
+        out.append((line, slices, m.group(2)))
+    return out
+
+
 def main():
+    par = _parabolic_literals(os.path.join(REF, "runtests.jl"))
+    names_par = [("fem1d_3nodes", dict(geom="fem1d", nodes=3)), ("fem2d_P2_L1", dict(geom="fem2d_P2", L=1)),
+                 ("spectral1d_n4", dict(geom="spectral1d", n=4)), ("spectral2d_n4", dict(geom="spectral2d", n=4))]
+    assert len(par) == len(names_par), len(par)
+    pcases = []
+    for (name, desc), (line, slices, call) in zip(names_par, par):
+        assert "h=0.5" in call and "p=1.0" in call, call
+        pcases.append(dict(name=name, source=f"test/runtests.jl:{line}", tol=1e-6, h=0.5, p=1.0, u=slices, **desc))
+    here0 = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here0, "golden_parabolic.json"), "w") as fh:
+        json.dump(dict(note="Golden parabolic_solve trajectories transcribed from the reference's test sources "
+                            "(u[time][node][component]; criterion norm(cat(u) - gold) < tol).", cases=pcases), fh, indent=1)
+    print("wrote", len(pcases), "parabolic cases")
     rt = _literals(os.path.join(REF, "runtests.jl"))
     ta = _literals(os.path.join(REF, "test_algebraic.jl"))
     cases = []

@@ -20,6 +20,25 @@ def build_case(c):
     return m.assemble(m.amg(geom), p=c["p"])
 
 
+def build_geom(c):
+    g = c["geom"]
+    if g == "fem1d":
+        return m.fem1d(nodes=np.linspace(-1, 1, c["nodes"]))
+    if g == "fem2d_P2":
+        return m.subdivide(m.fem2d_P2(), c["L"])
+    if g == "spectral1d":
+        return m.spectral1d(n=c["n"])
+    if g == "spectral2d":
+        return m.spectral2d(n=c["n"])
+    raise ValueError(g)
+
+
+def parabolic_goldens():
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_parabolic.json")) as fh:
+        return {c["name"]: c for c in json.load(fh)["cases"]}
+
+
 def gold_z(c):
     return np.array(c["z_colmajor"]).reshape(c["ncols"], -1).T
 

@@ -228,6 +228,26 @@ def test_spectral2d_dense_path_config5_family_matches_oracle(n, p):
     assert np.abs(sol.z - so["z"]).max() < 1e-8
 
 
+@pytest.mark.parametrize("name", ["fem1d_3nodes", "fem2d_P2_L1", "spectral1d_n4", "spectral2d_n4"])
+def test_parabolic_solve_reproduces_reference_golden(name):
+    """the time-stepping caller on ONE resident device image
+    (test/runtests.jl:35-52: three states, two power cones, phase I on every step)."""
+    from helpers import build_geom, parabolic_goldens
+    c = parabolic_goldens()[name]
+    sol = m.parabolic_solve(m.amg(build_geom(c)), h=c["h"], p=c["p"])
+    assert np.linalg.norm(np.stack(sol.u, axis=0) - np.array(c["u"])) < c["tol"]
+    assert all(s.SOL_feasibility is not None for s in sol.steps)
+
+
+def test_parabolic_solve_matches_oracle_on_a_refined_mesh():
+    mg = m.amg(m.subdivide(m.fem2d_P2(), 3))
+    kw = dict(h=0.25, t1=0.5, p=1.5, f1=lambda t, x: 0.5 + 0.25 * t * x[0])
+    sol = m.parabolic_solve(mg, **kw)
+    so = m.parabolic_solve(mg, solver=O.mgb_solve, **kw)
+    assert len(sol.u) == 3
+    assert np.abs(np.stack(sol.u) - np.stack(so.u)).max() < 1e-6
+
+
 def test_config2_size_properties_and_determinism():
     """fem2d_P2 p=1.5 L=7 (BASELINE configs[1]): size-independent properties instead of an oracle run."""
     prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 7)), p=1.5)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import mgb_amd as m
-from helpers import build_case, gold_z, lower_bound_problem
+from helpers import build_case, build_geom, gold_z, lower_bound_problem, parabolic_goldens
 from oracle import mgb_oracle as O
 
 CASES = ["fem1d_3nodes_p1", "fem2d_P2_L1_p1", "spectral1d_n5_p1", "spectral2d_n5_p1", "fem1d_5nodes_p1",
@@ -17,6 +17,17 @@ def test_oracle_reproduces_reference_golden(golden, name):
     c = golden[name]
     sol = O.mgb_solve(build_case(c))
     assert np.linalg.norm(sol["z"] - gold_z(c)) < c["tol"]
+
+
+@pytest.mark.parametrize("name", ["fem1d_3nodes", "fem2d_P2_L1", "spectral1d_n4", "spectral2d_n4"])
+def test_oracle_reproduces_reference_parabolic_golden(name):
+    # test/runtests.jl:35-52: three states (u, s1, s2), intersection of two power cones, phase I on
+    # every step (the start s1 = s2 = 0 is infeasible), implicit Euler with h = 0.5
+    c = parabolic_goldens()[name]
+    sol = m.parabolic_solve(m.amg(build_geom(c)), h=c["h"], p=c["p"], solver=O.mgb_solve)
+    u = np.stack(sol.u, axis=0)
+    assert u.shape == np.array(c["u"]).shape
+    assert np.linalg.norm(u - np.array(c["u"])) < c["tol"]
 
 
 def test_linear_cobarrier_hessian_known_answer():
