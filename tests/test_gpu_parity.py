@@ -228,6 +228,20 @@ def test_spectral2d_dense_path_config5_family_matches_oracle(n, p):
     assert np.abs(sol.z - so["z"]).max() < 1e-8
 
 
+def test_spectral2d_two_sided_obstacle_config5_matches_oracle():
+    """BASELINE configs[4]: spectral2d, p = 1.5 power cone intersected with the two-sided obstacle
+    -0.1 <= u <= 1 (reference pattern: src/Zoo/two_sided_obstacle.jl:23-49), dense path (144 nodes)."""
+    mg = m.amg(m.spectral2d(n=12))
+    nn = mg.geometry.w.size
+    Q = m.intersect(mg, m.convex_Euclidian_power(mg, idx=(2, 3, 4), p_grid=np.full(nn, 1.5)),
+                    m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[1.0], [-1.0]]), b=lambda x: np.array([0.1, 1.0])))
+    prob = m.assemble(mg, Q=Q, f_grid=np.tile([2.0, 0, 0, 0.5], (nn, 1)), g_grid=np.tile([0.0, 10.0], (nn, 1)))
+    sol = m.mgb_solve(prob)
+    so = O.mgb_solve(prob)
+    assert np.abs(sol.z - so["z"]).max() < 1e-7
+    assert sol.z[:, 0].min() > -0.1 and sol.z[:, 0].max() < 1.0          # the obstacle is respected
+
+
 @pytest.mark.parametrize("name", ["fem1d_3nodes", "fem2d_P2_L1", "spectral1d_n4", "spectral2d_n4"])
 def test_parabolic_solve_reproduces_reference_golden(name):
     """the time-stepping caller on ONE resident device image
