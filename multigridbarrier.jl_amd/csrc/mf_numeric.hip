@@ -788,6 +788,129 @@ __global__ __launch_bounds__(256) void mf_bwd_big_step(const FrontDev* __restric
 }
 
 
+// ---- leaf fronts with m <= 16 (the static-condensation leaves: one per element) -----------------
+// A wave-per-front kernel leaves 3/4 of its lanes idle on these and pays a full LDS instruction
+// per handful of entries.  Here 16 lanes own one front (4 fronts per wave, 16 per workgroup):
+// lane r keeps row r of the front in registers, the column of multipliers is exchanged through a
+// 16-double LDS line per front, and the triangular solves use width-16 shuffles.
+__global__ __launch_bounds__(256) void mf_factor_tiny(const FrontDev* __restrict__ fr, int32_t first, int32_t count,
+                                                      const int32_t* __restrict__ a_src,
+                                                      const int32_t* __restrict__ a_dst,
+                                                      const double* __restrict__ Hval, double* __restrict__ arena,
+                                                      int32_t* __restrict__ status) {
+    __shared__ double Wt[16][256];
+    __shared__ double colb[16][16];
+    const int g = threadIdx.x >> 4, r = threadIdx.x & 15;
+    const int fi = blockIdx.x * 16 + g;
+    const bool on = fi < count;
+    const FrontDev F = fr[first + (on ? fi : 0)];
+    const int m = F.m, k = on ? F.k : 0;
+    double* W = Wt[g];
+    for (int i = r; i < 256; i += 16) W[i] = 0.0;
+    wave_sync();
+    if (on)
+        for (int t = r; t < F.a_cnt; t += 16) W[a_dst[F.a_off + t]] = Hval[a_src[F.a_off + t]];
+    wave_sync();
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = (on && r < m && c <= r) ? W[r + c * m] : 0.0;
+    int kmax = k;
+    kmax = max(kmax, __shfl_xor(kmax, 16, 64));
+    kmax = max(kmax, __shfl_xor(kmax, 32, 64));
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j >= kmax) break;
+        colb[g][r] = a[j];
+        wave_sync();
+        const bool act = j < k;
+        const double d = colb[g][j];
+        if (act && (d == 0.0 || !isfinite(d))) bad = true;
+        const double lr = a[j] * fast_recip(act ? d : 1.0);
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+            const double v = colb[g][c];          // entry (c, j); rows >= m hold zeros
+            if (act) a[c] -= lr * v;
+        }
+        if (act && r > j) a[j] = lr;
+        wave_sync();
+    }
+    if (bad) atomicOr(status, 1);
+    if (on && r < m) {
+        double* Fg = arena + F.F_off;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c <= r) Fg[r + (int64_t)c * m] = a[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void mf_forward_tiny(const FrontDev* __restrict__ fr, int32_t first, int32_t count,
+                                                       const int32_t* __restrict__ front_idx,
+                                                       const double* __restrict__ arena,
+                                                       const double* __restrict__ b, double* __restrict__ y,
+                                                       double* __restrict__ uvec) {
+    const int g = threadIdx.x >> 4, r = threadIdx.x & 15;
+    const int fi = blockIdx.x * 16 + g;
+    const bool on = fi < count;
+    const FrontDev F = fr[first + (on ? fi : 0)];
+    const int m = F.m, k = on ? F.k : 0;
+    const int32_t* idx = front_idx + F.idx_off;
+    const double* Fm = arena + F.F_off;
+    const bool row = on && r < m;
+    const int myidx = row ? idx[r] : 0;
+    double t = (row && r < k) ? b[myidx] : 0.0;
+    double l[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) l[j] = (row && j < k && r > j) ? Fm[r + (int64_t)j * m] : 0.0;
+    const double dr = (row && r < k) ? Fm[r + (int64_t)r * m] : 1.0;
+    int kmax = k;
+    kmax = max(kmax, __shfl_xor(kmax, 16, 64));
+    kmax = max(kmax, __shfl_xor(kmax, 32, 64));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j >= kmax) break;
+        const double tj = __shfl(t, j, 16);
+        t -= l[j] * tj;                            // l[j] = 0 outside (j < k, r > j)
+    }
+    if (row) {
+        if (r < k) y[myidx] = t / dr;
+        else uvec[F.u_off + r - k] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void mf_backward_tiny(const FrontDev* __restrict__ fr, int32_t first, int32_t count,
+                                                        const int32_t* __restrict__ front_idx,
+                                                        const double* __restrict__ arena,
+                                                        const double* __restrict__ y, double* __restrict__ x) {
+    const int g = threadIdx.x >> 4, r = threadIdx.x & 15;
+    const int fi = blockIdx.x * 16 + g;
+    const bool on = fi < count;
+    const FrontDev F = fr[first + (on ? fi : 0)];
+    const int m = F.m, k = on ? F.k : 0;
+    const int32_t* idx = front_idx + F.idx_off;
+    const double* Fm = arena + F.F_off;
+    const bool row = on && r < m;
+    const int myidx = row ? idx[r] : 0;
+    double t = row ? ((r < k) ? y[myidx] : x[myidx]) : 0.0;
+    double l[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) l[j] = (row && j < k && r > j) ? Fm[r + (int64_t)j * m] : 0.0;
+    int kmax = k;
+    kmax = max(kmax, __shfl_xor(kmax, 16, 64));
+    kmax = max(kmax, __shfl_xor(kmax, 32, 64));
+#pragma unroll
+    for (int j = 15; j >= 0; --j) {
+        if (j >= kmax) continue;
+        double s = l[j] * t;                       // rows r > j of column j (zero elsewhere)
+        s += __shfl_xor(s, 8, 16);
+        s += __shfl_xor(s, 4, 16);
+        s += __shfl_xor(s, 2, 16);
+        s += __shfl_xor(s, 1, 16);
+        if (r == j && j < k) t -= s;
+    }
+    if (row && r < k) x[myidx] = t;
+}
+
 // ---- large-front triangular solves, one workgroup per front -----------------------------------
 // The block steps of a triangular solve are a chain of dependent latencies (diagonal block ->
 // row update -> next diagonal block); the arithmetic is tiny.  One 1024-thread workgroup per
@@ -990,6 +1113,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             L.cls = cls;
             L.max_m = plan.fronts[j - 1].m;
             L.max_k = 0;
+            L.tiny = (l == 0 && cls == 16);     // leaves with m <= 16: 16 lanes per front
             for (int32_t q = i; q < j; ++q) L.max_k = std::max(L.max_k, plan.fronts[q].k);
             level_launches[l].push_back(L);
             i = j;
@@ -1000,7 +1124,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     for (int32_t l = 0; l < nlev; ++l) {
         MfLaunch S{};
         for (auto& L : level_launches[l]) {
-            if (!L.cls) { level_solves[l].push_back(L); continue; }
+            if (!L.cls || L.tiny) { level_solves[l].push_back(L); continue; }
             if (S.count == 0) S = L;
             else {
                 S.count += L.count;
@@ -1042,7 +1166,10 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
     for (auto& lev : level_launches)
         for (auto& L : lev) {
             if (L.count == 0) continue;
-            if (L.cls) {
+            if (L.tiny) {
+                hipLaunchKernelGGL(mf_factor_tiny, dim3((L.count + 15) / 16), dim3(256), 0, st, d_fronts.p, L.first,
+                                   L.count, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+            } else if (L.cls) {
                 size_t lds = (size_t)L.cls * L.cls * sizeof(double);
                 static const int exp_mask = [] { const char* e = getenv("MGBHIP_EXP"); return e ? atoi(e) : 0; }();
                 static const int nbt_mid = [] { const char* e = getenv("MGBHIP_NBT"); return e ? atoi(e) : 8; }();
@@ -1085,7 +1212,10 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
     for (auto& lev : level_solves)
         for (auto& L : lev) {
             if (L.count == 0) continue;
-            if (L.cls) {
+            if (L.tiny) {
+                hipLaunchKernelGGL(mf_forward_tiny, dim3((L.count + 15) / 16), dim3(256), 0, st, d_fronts.p, L.first,
+                                   L.count, d_front_idx.p, d_arena.p, d_b, d_y.p, d_uvec.p);
+            } else if (L.cls) {
                 const int ts = (L.max_m + 1) & ~1;
                 hipLaunchKernelGGL(mf_forward_small, dim3((L.count + 3) / 4), dim3(256), (size_t)4 * ts * sizeof(double),
                                    st, d_fronts.p, L.first, L.count, ts, d_front_idx.p, d_children.p, d_rel.p,
@@ -1112,7 +1242,10 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
         for (auto it = level_solves[l].rbegin(); it != level_solves[l].rend(); ++it) {
             const MfLaunch& L = *it;
             if (L.count == 0) continue;
-            if (L.cls) {
+            if (L.tiny) {
+                hipLaunchKernelGGL(mf_backward_tiny, dim3((L.count + 15) / 16), dim3(256), 0, st, d_fronts.p, L.first,
+                                   L.count, d_front_idx.p, d_arena.p, d_y.p, d_x);
+            } else if (L.cls) {
                 hipLaunchKernelGGL(mf_backward_small, dim3((L.count + 3) / 4), dim3(256), 0, st, d_fronts.p, L.first,
                                    L.count, d_front_idx.p, d_arena.p, d_y.p, d_x);
             } else if (L.max_m <= BIG1_MAX_M) {

@@ -19,6 +19,7 @@ struct MfLaunch {          // one kernel launch: a contiguous range of fronts of
     int32_t first, count;
     int32_t cls;           // LDS working size (0 = large-front multi-workgroup path)
     int32_t max_m, max_k;  // largest front / pivot block in the range
+    bool tiny = false;     // leaf fronts with m <= 16: 16-lanes-per-front kernels
 };
 
 class MfSolver {
