@@ -1,0 +1,146 @@
+"""Boundary behaviour of the C ABI on the GPU: malformed descriptors are refused with
+MGBHIP_ERR_INVALID and a message (never a crash, never a CPU fallback); numerical infeasibility
+is a value, not an error; the smallest meshes and a singular system."""
+import numpy as np
+import pytest
+
+import mgb_amd as m
+from mgb_amd import device as dev
+from helpers import stacked
+from oracle import mgb_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+INVALID, NOT_SPD = 1, 3
+
+
+class _MutatingLib:
+    """Forwards to libmgbhip but lets a test edit the descriptor just before problem_create."""
+
+    def __init__(self, lib, mutate):
+        self._lib, self._mutate = lib, mutate
+
+    def __getattr__(self, name):
+        return getattr(self._lib, name)
+
+    def mgbhip_problem_create(self, ctx, dref, share, out):
+        self._mutate(dref._obj)
+        return self._lib.mgbhip_problem_create(ctx, dref, share, out)
+
+
+def _small_problem():
+    return m.assemble(m.amg(m.fem1d(nodes=np.linspace(-1, 1, 5))), p=1.5)
+
+
+def _set(path, value):
+    def mutate(d):
+        obj = d
+        for key in path[:-1]:
+            obj = obj[key] if isinstance(key, int) else getattr(obj, key)
+        if isinstance(path[-1], int):
+            obj[path[-1]] = value
+        else:
+            setattr(obj, path[-1], value)
+    return mutate
+
+
+def _shrink_rows(d):
+    d.R[0].rows -= 1
+
+
+@pytest.mark.parametrize("mutate", [
+    _set(("p",), 0), _set(("N",), 0), _set(("nu",), 0), _set(("nu",), 9), _set(("nD",), 0), _set(("nD",), 64),
+    _set(("n_ops",), 0), _set(("L",), 0), _set(("D_state", 1), 7), _set(("D_op", 1), 6),
+    _set(("cone", "npieces"), 0), _set(("cone", "npieces"), 9), _set(("cone", "pieces", 0, "kind"), 99),
+    _set(("cone", "pieces", 0, "ni"), 0), _set(("cone", "pieces", 0, "idx", 0), 17), _shrink_rows,
+])
+def test_malformed_descriptor_is_refused_with_a_message(mutate):
+    prob = _small_problem()
+    ctx = dev.HipContext(0)
+    real = ctx.lib
+    ctx.lib = _MutatingLib(real, mutate)
+    try:
+        with pytest.raises(dev.MGBHipError) as ei:
+            dev.DeviceProblem(ctx, dev.dense_as_block(prob.M[0]), prob.Q)
+        assert ei.value.status == INVALID
+        assert len(str(ei.value)) > 30          # mgbhip_last_error() carries the reason
+    finally:
+        ctx.lib = real
+        ctx.close()
+
+
+def test_out_of_range_level_and_solve_before_assembly():
+    prob = _small_problem()
+    D = dev.DeviceMGBProblem(prob)
+    try:
+        P = D.main
+        L = len(P.level_sizes)
+        z0, c = stacked(prob.g), 0.1 * prob.f
+        for bad in (-1, L, L + 5):
+            with pytest.raises(dev.MGBHipError) as ei:
+                P.f0(bad, np.zeros(1), c, z0)
+            assert ei.value.status == INVALID
+        with pytest.raises(dev.MGBHipError) as ei:
+            P.solve(L - 1, np.ones(P.level_sizes[L - 1]))          # no Hessian assembled yet
+        assert ei.value.status == INVALID
+    finally:
+        D.close()
+
+
+def test_nonfinite_inputs_propagate_as_values():
+    prob = _small_problem()
+    D = dev.DeviceMGBProblem(prob)
+    try:
+        P = D.main
+        J = len(P.level_sizes) - 1
+        z0, c = stacked(prob.g), 0.1 * prob.f
+        s = np.zeros(P.level_sizes[J])
+        s[0] = np.nan
+        assert np.isnan(P.f0(J, s, c, z0))                         # a value, like the reference's Log protocol
+        assert not np.all(np.isfinite(P.f1(J, s, c, z0)))
+        s[0] = 1e300                                               # far outside the cone: +Inf / NaN, no error
+        assert not np.isfinite(P.f0(J, s, c, z0))
+    finally:
+        D.close()
+
+
+def test_singular_hessian_reports_not_spd():
+    prob = _small_problem()
+    D = dev.DeviceMGBProblem(prob)
+    try:
+        P = D.main
+        J = len(P.level_sizes) - 1
+        P.set_barrier_weights(np.zeros(prob.M[0].w.size))          # barrier switched off everywhere: H = 0
+        z0 = stacked(prob.g)
+        P.f2(J, np.zeros(P.level_sizes[J]), 0.1 * prob.f, z0)
+        with pytest.raises(dev.MGBHipError) as ei:
+            P.solve(J, np.ones(P.level_sizes[J]))
+        assert ei.value.status == NOT_SPD
+    finally:
+        D.close()
+
+
+@pytest.mark.parametrize("geom", ["fem1d_1element", "fem2d_P2_2elements", "fem3d_1element", "spectral1d_n2"])
+def test_smallest_meshes_match_oracle(geom):
+    g = {"fem1d_1element": lambda: m.fem1d(nodes=np.array([-1.0, 1.0])),
+         "fem2d_P2_2elements": lambda: m.fem2d_P2(),
+         "fem3d_1element": lambda: m.fem3d(k=1),
+         "spectral1d_n2": lambda: m.spectral1d(n=2)}[geom]()
+    prob = m.assemble(m.amg(g), p=1.5)
+    sol = m.mgb_solve(prob)
+    so = O.mgb_solve(prob)
+    assert np.abs(sol.z - so["z"]).max() < 1e-8
+
+
+def test_handles_are_independent_and_reusable():
+    """Two images on one context and repeated solves on one image (the reference flushes its
+    caches per solve, src/mgb.jl:840; a handle here keeps plans and symbolic factorizations)."""
+    pa = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 2)), p=1.0)
+    pb = m.assemble(m.amg(m.fem1d(nodes=np.linspace(-1, 1, 9))), p=2.0)
+    sa = m.mgb_solve(pa, keep_device=True)
+    sb = m.mgb_solve(pb)
+    from mgb_amd.solve import mgb_driver
+    again = mgb_driver(sa.device)
+    sa.device.close()
+    assert np.array_equal(again["z"], sa.z)
+    assert np.abs(sb.z - O.mgb_solve(pb)["z"]).max() < 1e-8
