@@ -579,7 +579,28 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
     while (ti * (ti + 1) / 2 > lin) --ti;
     const int tj = lin - ti * (ti + 1) / 2;
     if (ti >= T) return;
-    if (tid < nb) dq[tid] = src[tid + NB * tid];
+    // One round of global loads: the pivots d_q, the two 64 x 32 panel slices and this thread's
+    // 4 x 4 micro-tile of the trailing block are all requested before anything waits (the
+    // scaling by d_q happens on the LDS side, the micro-tile is consumed after the products).
+    if (tid < NB) dq[tid] = (tid < nb) ? src[tid + NB * tid] : 0.0;
+    const int rbase = j1 + ti * ST, cbase = j1 + tj * ST;
+    const int tx = tid % 16, ty = tid / 16;
+    double wt[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int c = cbase + ty + 16 * b;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int r = rbase + tx + 16 * a;
+            wt[a][b] = (c < m && r < m && r >= c) ? W[r + (int64_t)c * m] : 0.0;
+        }
+    }
+    for (int i = tid; i < NB * ST; i += 256) {
+        const int rr = i % ST, q = i / ST;
+        const int r = rbase + rr, c = cbase + rr;
+        Pi[q][rr] = (q < nb && r < m) ? W[r + (int64_t)(j0 + q) * m] : 0.0;
+        Qj[q][rr] = (q < nb && c < m) ? W[c + (int64_t)(j0 + q) * m] : 0.0;
+    }
     if (lin == 0) {
         for (int i = tid; i < nb * nb; i += 256) {
             const int r = i % nb, c = i / nb;
@@ -587,24 +608,17 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
         }
     }
     __syncthreads();
-    const int rbase = j1 + ti * ST, cbase = j1 + tj * ST;
-    for (int i = tid; i < nb * ST; i += 256) {
-        const int rr = i % ST, q = i / ST;
-        const int r = rbase + rr, c = cbase + rr;
-        Pi[q][rr] = (r < m) ? W[r + (int64_t)(j0 + q) * m] : 0.0;
-        Qj[q][rr] = (c < m) ? W[c + (int64_t)(j0 + q) * m] * dq[q] : 0.0;
-    }
-    __syncthreads();
-    const int tx = tid % 16, ty = tid / 16;
     double acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int q = 0; q < nb; ++q) {
+#pragma unroll 4
+    for (int q = 0; q < NB; ++q) {              // rows q >= nb of Pi/Qj and dq hold zeros
         double pr[4], qc[4];
+        const double d = dq[q];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) pr[a] = Pi[q][tx + 16 * a];
+        for (int a = 0; a < 4; ++a) pr[a] = Pi[q][tx + 16 * a] * d;
 #pragma unroll
         for (int b = 0; b < 4; ++b) qc[b] = Qj[q][ty + 16 * b];
 #pragma unroll
@@ -620,7 +634,7 @@ __global__ __launch_bounds__(256) void mf_big_update(const FrontDev* __restrict_
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int r = rbase + tx + 16 * a;
-            if (r < m && r >= c && !(r - j1 < nskip && c - j1 < nskip)) W[r + (int64_t)c * m] -= acc[a][b];
+            if (r < m && r >= c && !(r - j1 < nskip && c - j1 < nskip)) W[r + (int64_t)c * m] = wt[a][b] - acc[a][b];
         }
     }
 }
