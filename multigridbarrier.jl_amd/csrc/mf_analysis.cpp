@@ -388,7 +388,9 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
         }
         // A entries owned by this front: pairs {v,u}, v a pivot, u == v or eliminated later
         f.a_off = (int64_t)plan.a_src.size();
+        f.acol_off = (int64_t)plan.a_colptr.size();
         for (int32_t lv = 0; lv < f.k; ++lv) {
+            plan.a_colptr.push_back((int32_t)((int64_t)plan.a_src.size() - f.a_off));
             int32_t v = idx[lv];
             for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
                 int32_t u = colidx[e];
@@ -408,6 +410,7 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
             }
         }
         f.a_cnt = (int32_t)((int64_t)plan.a_src.size() - f.a_off);
+        plan.a_colptr.push_back(f.a_cnt);
         for (int32_t j = 0; j < f.m; ++j) loc[idx[j]] = -1;
     }
 }

@@ -33,6 +33,7 @@ struct Front {
     int64_t rel_off = 0;      // into MfPlan::rel: (m-k) positions of this front's boundary in its parent
     int64_t a_off = 0;        // into MfPlan::a_src / a_dst
     int32_t a_cnt = 0;
+    int64_t acol_off = 0;     // into MfPlan::a_colptr (k + 1 entries: A entries of pivot column c are [ptr[c], ptr[c+1]))
 };
 
 struct MfPlan {
@@ -43,6 +44,7 @@ struct MfPlan {
     std::vector<int32_t> rel;           // concatenated relative indices
     std::vector<int32_t> a_src;         // CSR value index of H feeding a_dst
     std::vector<int32_t> a_dst;         // position row + col*m inside the front
+    std::vector<int32_t> a_colptr;      // per front, per pivot column: offsets into its A entries (relative to a_off)
     std::vector<int32_t> level_ptr;     // fronts [level_ptr[l], level_ptr[l+1]) are level l
     int64_t arena_doubles = 0;          // sum m*m
     int64_t uvec_doubles = 0;           // sum (m-k)

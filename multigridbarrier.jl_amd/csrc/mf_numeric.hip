@@ -37,6 +37,7 @@ constexpr int NB = 32;    // panel width of the large-front path
 constexpr int CT = 8;     // destination columns per workgroup in the large-front assembly (2 per wave)
 constexpr int TR = 256;   // rows per workgroup in the panel solve
 constexpr int ST = 64;    // tile edge of the symmetric update
+constexpr int ASM_REL_LDS = 2048; // relative indices of one child kept in LDS by the large-front assembly
 constexpr int CHILD_CHUNK = 64;   // child descriptors staged in LDS at a time
 
 // ------------------------------------------------------------------------------------------------
@@ -364,7 +365,9 @@ __global__ __launch_bounds__(256) void mf_big_assemble(const FrontDev* __restric
                                                        const int32_t* __restrict__ rel,
                                                        const int32_t* __restrict__ a_src,
                                                        const int32_t* __restrict__ a_dst,
+                                                       const int32_t* __restrict__ a_colptr,
                                                        const double* __restrict__ Hval, double* __restrict__ arena) {
+    __shared__ int32_t rls[ASM_REL_LDS];
     const FrontDev F = fr[first + blockIdx.y];
     const int m = F.m;
     const int c0 = blockIdx.x * CT;
@@ -378,22 +381,25 @@ __global__ __launch_bounds__(256) void mf_big_assemble(const FrontDev* __restric
         for (int r = c + lane; r < m; r += 64) Wc[r] = 0.0;
     }
     __syncthreads();
-    {   // A entries are ordered by destination column: binary search the range of [c0, c1)
+    {   // A entries are grouped by pivot column: the per-column offsets give the range of [c0, c1)
+        const int32_t* cp = a_colptr + F.acol_off;
+        const int beg = cp[min(c0, F.k)], end = cp[min(c1, F.k)];
         const int32_t* ad = a_dst + F.a_off;
-        int lo = 0, hi = F.a_cnt;
-        const int64_t key0 = (int64_t)c0 * m, key1 = (int64_t)c1 * m;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (ad[mid] < key0) lo = mid + 1; else hi = mid; }
-        int beg = lo;
-        hi = F.a_cnt;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (ad[mid] < key1) lo = mid + 1; else hi = mid; }
-        for (int t = beg + tid; t < lo; t += 256) W[ad[t]] = Hval[a_src[F.a_off + t]];
+        for (int t = beg + tid; t < end; t += 256) W[ad[t]] = Hval[a_src[F.a_off + t]];
     }
     __syncthreads();
     for (int c = 0; c < F.nchild; ++c) {
         const FrontDev C = fr[children[F.child_off + c]];
         const double* U = arena + C.F_off;
         const int mc = C.m, kc = C.k, b = mc - kc;
-        const int32_t* rl = rel + C.rel_off;
+        const int32_t* rlg = rel + C.rel_off;
+        // relative indices of this child in LDS: the two searches and the scatter below read them
+        // from there instead of chasing ~2 log2(b) dependent global loads
+        const bool in_lds = b <= ASM_REL_LDS;
+        if (in_lds)
+            for (int j = tid; j < b; j += 256) rls[j] = rlg[j];
+        __syncthreads();
+        const int32_t* rl = in_lds ? rls : rlg;
         // child columns whose destination lies in [c0, c1): rel is increasing
         int lo = 0, hi = b;
         while (lo < hi) { int mid = (lo + hi) >> 1; if (rl[mid] < c0) lo = mid + 1; else hi = mid; }
@@ -1075,7 +1081,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     std::vector<FrontDev> fd(nf);
     for (int32_t i = 0; i < nf; ++i) {
         const Front& f = plan.fronts[i];
-        fd[i] = FrontDev{f.k, f.m, f.nchild, f.a_cnt, f.F_off, f.idx_off, f.u_off, f.child_off, f.rel_off, f.a_off};
+        fd[i] = FrontDev{f.k, f.m, f.nchild, f.a_cnt, f.F_off, f.idx_off, f.u_off, f.child_off, f.rel_off, f.a_off, f.acol_off};
     }
     d_fronts.upload(fd, st);
     d_front_idx.upload(plan.front_idx, st);
@@ -1083,6 +1089,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     d_rel.upload(plan.rel, st);
     d_a_src.upload(plan.a_src, st);
     d_a_dst.upload(plan.a_dst, st);
+    d_a_colptr.upload(plan.a_colptr, st);
     d_arena.alloc((size_t)std::max<int64_t>(plan.arena_doubles, 1));
     d_uvec.alloc((size_t)std::max<int64_t>(plan.uvec_doubles, 1));
     d_y.alloc((size_t)std::max<int64_t>(plan.n, 1));
@@ -1201,7 +1208,7 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
             } else {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
                 hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,
-                                   d_a_src.p, d_a_dst.p, d_values, d_arena.p);
+                                   d_a_src.p, d_a_dst.p, d_a_colptr.p, d_values, d_arena.p);
                 for (int j0 = 0; j0 < L.max_k; j0 += NB) {
                     const int rem = L.max_m - j0;                // rows from the panel start, at most
                     const dim3 gp(std::max(1, (rem - 1 + TR - 1) / TR), L.count);
