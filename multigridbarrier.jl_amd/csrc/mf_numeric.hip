@@ -128,6 +128,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     __shared__ int64_t cU[CHILD_CHUNK];        // arena offset of the child's update block (kc, kc)
     __shared__ int64_t cR[CHILD_CHUNK];        // rel offset
     __shared__ int32_t cM[CHILD_CHUNK], cB[CHILD_CHUNK];
+    __shared__ int32_t crl[128];               // relative indices of one larger child (b <= m <= 128)
     for (int cbase = 0; cbase < ((exp_mask & 1) ? 0 : F.nchild); cbase += CHILD_CHUNK) {
         const int nc = min(CHILD_CHUNK, F.nchild - cbase);
         __syncthreads();
@@ -165,21 +166,25 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                 if (c >= nc) break;
                 if (dst[u] >= 0) W[dst[u]] += val[u];
                 const int b = cB[c];
-                if (b * b > nt) {               // larger child: 2-D sweep, two rows per lane in flight
-                    const int32_t* rl = rel + cR[c];
+                if (b * b > nt) {               // larger child: 2-D sweep, relative indices from LDS
+                    const int32_t* rlg = rel + cR[c];
+                    for (int j = tid; j < b; j += nt) crl[j] = rlg[j];
+                    __syncthreads();
                     const double* U = arena + cU[c];
                     const int mc = cM[c];
                     for (int j = ty; j < b; j += TYn) {
-                        const int dcol = rl[j] * m;
+                        const int dcol = crl[j] * m;
                         const double* Uc = U + (int64_t)j * mc;
-                        for (int r = j + tx; r < b; r += 2 * TX) {
-                            const int r1 = r + TX;
-                            const int i0 = rl[r];
-                            const int i1 = r1 < b ? rl[r1] : i0;
+                        for (int r = j + tx; r < b; r += 4 * TX) {      // four rows per lane in flight
+                            const int r1 = r + TX, r2 = r + 2 * TX, r3 = r + 3 * TX;
                             const double u0 = Uc[r];
                             const double u1 = r1 < b ? Uc[r1] : 0.0;
-                            W[i0 + dcol] += u0;
-                            if (r1 < b) W[i1 + dcol] += u1;
+                            const double u2 = r2 < b ? Uc[r2] : 0.0;
+                            const double u3 = r3 < b ? Uc[r3] : 0.0;
+                            W[crl[r] + dcol] += u0;
+                            if (r1 < b) W[crl[r1] + dcol] += u1;
+                            if (r2 < b) W[crl[r2] + dcol] += u2;
+                            if (r3 < b) W[crl[r3] + dcol] += u3;
                         }
                     }
                 }
