@@ -114,6 +114,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     const int tid = threadIdx.x, nt = blockDim.x;
     const int tx = tid % TX, ty = tid / TX, TYn = nt / TX;
     const int mm = m * m;
+    double* S = W + mm;                        // [NBT][m] scaled multipliers of the current panel
 
     for (int i = tid; i < mm; i += nt) W[i] = 0.0;
     __syncthreads();
@@ -221,24 +222,44 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                         a[c] = v;
                     }
                 }
+                // a[c] is still l(r, c) * d_c here: exactly the scaled multiplier the update needs
 #pragma unroll
-                for (int c = 0; c < NBT; ++c)
+                for (int c = 0; c < NBT; ++c) {
+                    S[c * m + r] = (c < nb) ? a[c] : 0.0;
                     if (c < nb) W[r + (j0 + c) * m] = a[c] / W[(j0 + c) + (j0 + c) * m];
+                }
             }
         }
         __syncthreads();
+        // rank-nb update of the trailing lower triangle, two columns x four rows per thread and
+        // pass: the eight multipliers of a row are read once for both columns, the scaled ones
+        // S(q, c) = l(c, q) d_q come straight from the row solve above
         const int c0 = j0 + nb;
-        for (int c = c0 + ty; c < m; c += TYn) {
-            double mult[NBT];
+        for (int c = c0 + ty; c < m; c += 2 * TYn) {
+            const int c2 = c + TYn;
+            const bool two = c2 < m;
+            double s1[NBT], s2[NBT];
 #pragma unroll
-            for (int q = 0; q < NBT; ++q) mult[q] = (q < nb) ? W[c + (j0 + q) * m] * W[(j0 + q) + (j0 + q) * m] : 0.0;
-            double* Wc = W + c * m;
-            for (int r = c + tx; r < m; r += TX) {
-                double acc = 0.0;
+            for (int q = 0; q < NBT; ++q) {
+                s1[q] = S[q * m + c];
+                s2[q] = two ? S[q * m + c2] : 0.0;
+            }
+            for (int r = c + tx; r < m; r += 4 * TX) {
 #pragma unroll
-                for (int q = 0; q < NBT; ++q)
-                    if (q < nb) acc += W[r + (j0 + q) * m] * mult[q];
-                Wc[r] -= acc;
+                for (int i = 0; i < 4; ++i) {
+                    const int ri = r + i * TX;
+                    if (ri < m) {
+                        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                        for (int q = 0; q < NBT; ++q) {
+                            const double l = (q < nb) ? W[ri + (j0 + q) * m] : 0.0;
+                            a1 += l * s1[q];
+                            a2 += l * s2[q];
+                        }
+                        W[ri + c * m] -= a1;
+                        if (two && ri >= c2) W[ri + c2 * m] -= a2;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -1106,11 +1127,11 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     // dynamic LDS above 64 KB needs an explicit opt-in; fall back to the 64 KB classes if refused
     lds_cap = 88;
     if (hipFuncSetAttribute((const void*)mf_factor_small<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            128 * 128 * 8) == hipSuccess &&
+                            (128 * 128 + 16 * 128) * 8) == hipSuccess &&
         hipFuncSetAttribute((const void*)mf_factor_small<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            128 * 128 * 8) == hipSuccess &&
+                            (128 * 128 + 16 * 128) * 8) == hipSuccess &&
         hipFuncSetAttribute((const void*)mf_factor_small<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            128 * 128 * 8) == hipSuccess)
+                            (128 * 128 + 16 * 128) * 8) == hipSuccess)
         lds_cap = 128;
     else
         (void)hipGetLastError();
@@ -1196,11 +1217,12 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 hipLaunchKernelGGL(mf_factor_tiny, dim3((L.count + 15) / 16), dim3(256), 0, st, d_fronts.p, L.first,
                                    L.count, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
             } else if (L.cls) {
-                size_t lds = (size_t)L.cls * L.cls * sizeof(double);
                 static const int exp_mask = [] { const char* e = getenv("MGBHIP_EXP"); return e ? atoi(e) : 0; }();
                 static const int nbt_mid = [] { const char* e = getenv("MGBHIP_NBT"); return e ? atoi(e) : 8; }();
                 const int threads = L.cls <= 16 ? 64 : (L.cls <= 32 ? 128 : 256);
-                const int nbt = L.cls <= 16 ? 8 : nbt_mid;
+                const int nbt = L.cls <= 16 ? 8 : std::min(nbt_mid, 16);    // 32-column LDS panels do not fit beside a 128 x 128 front
+                const int nbt_alloc = nbt <= 8 ? 8 : (nbt <= 16 ? 16 : 32);
+                const size_t lds = (size_t)(L.cls * L.cls + nbt_alloc * L.cls) * sizeof(double);    // front + scaled panel
                 if (nbt <= 8)
                     hipLaunchKernelGGL(mf_factor_small<8>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
                                        d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p, exp_mask);
