@@ -130,6 +130,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     __shared__ int64_t cR[CHILD_CHUNK];        // rel offset
     __shared__ int32_t cM[CHILD_CHUNK], cB[CHILD_CHUNK];
     __shared__ int32_t crl[128];               // relative indices of one larger child (b <= m <= 128)
+    __shared__ double prinv[32];               // reciprocal pivots of the current panel
     for (int cbase = 0; cbase < ((exp_mask & 1) ? 0 : F.nchild); cbase += CHILD_CHUNK) {
         const int nc = min(CHILD_CHUNK, F.nchild - cbase);
         __syncthreads();
@@ -203,7 +204,10 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
             bad |= wave_ldlt_regs<NBT>(a, nb, tid);
 #pragma unroll
             for (int c = 0; c < NBT; ++c)
-                if (tid < nb && c <= tid) W[(j0 + tid) + (j0 + c) * m] = a[c];
+                if (tid < nb && c <= tid) {
+                    W[(j0 + tid) + (j0 + c) * m] = a[c];
+                    if (c == tid) prinv[c] = 1.0 / a[c];      // pivot reciprocals for the row solves
+                }
         }
         __syncthreads();
         {                                     // panel rows: l = (a L11^{-T}) D^{-1}, one row per thread
@@ -226,7 +230,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
 #pragma unroll
                 for (int c = 0; c < NBT; ++c) {
                     S[c * m + r] = (c < nb) ? a[c] : 0.0;
-                    if (c < nb) W[r + (j0 + c) * m] = a[c] / W[(j0 + c) + (j0 + c) * m];
+                    if (c < nb) W[r + (j0 + c) * m] = a[c] * prinv[c];
                 }
             }
         }
