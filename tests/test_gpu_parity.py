@@ -262,6 +262,67 @@ def test_parabolic_solve_matches_oracle_on_a_refined_mesh():
     assert np.abs(np.stack(sol.u) - np.stack(so.u)).max() < 1e-6
 
 
+def _full_size_properties(prob, scale, check_solve=True):
+    """Size-independent properties at a BASELINE config's full size (no oracle run): symmetry,
+    f1 = grad f0, f2 = Jacobian of f1 (central differences along a random direction), direct-solve
+    residual, positive Newton decrement, bitwise reproducibility."""
+    D = _device(prob)
+    try:
+        P = D.main
+        J = len(P.level_sizes) - 1
+        rng = np.random.default_rng(23)
+        z0, c = stacked(prob.g), 0.1 * prob.f
+        s = scale * rng.standard_normal(P.level_sizes[J])
+        assert np.isfinite(P.f0(J, s, c, z0))
+        g = P.f1(J, s, c, z0)
+        # unit direction with a component along g: the directional derivative stays well above the
+        # rounding floor eps*|f0|/h of the central difference at any problem size
+        d = rng.standard_normal(P.level_sizes[J])
+        d = d / np.linalg.norm(d) + g / np.linalg.norm(g)
+        d /= np.linalg.norm(d)
+        H = P.f2(J, s, c, z0)
+        assert abs(H - H.T).max() <= 1e-12 * abs(H).max()
+        h = 10 * scale
+        fd = (P.f0(J, s + h * d, c, z0) - P.f0(J, s - h * d, c, z0)) / (2 * h)
+        assert abs(fd - g @ d) <= 1e-5 * abs(g @ d)
+        gd = (P.f1(J, s + h * d, c, z0) - P.f1(J, s - h * d, c, z0)) / (2 * h)
+        assert rel(gd, H @ d) <= 1e-4
+        if check_solve:
+            x = P.solve(J, g)
+            assert np.linalg.norm(H @ x - g) <= 1e-8 * np.linalg.norm(g)
+            assert g @ x > 0
+            assert np.array_equal(x, P.solve(J, g))
+        H2 = P.f2(J, s, c, z0)
+        assert np.array_equal(np.asarray(H.data if sp.issparse(H) else H), np.asarray(H2.data if sp.issparse(H2) else H2))
+    finally:
+        D.close()
+
+
+def test_config3_full_size_properties():
+    """fem2d_P2 p=1.0 L=9 (BASELINE configs[2], the headline size: 917 504 nodes, 1.31 M unknowns)."""
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 9), prolongator=m.amg_ruge_stuben(max_coarse=300)), p=1.0)
+    _full_size_properties(prob, 1e-5)
+
+
+def test_config4_full_size_properties():
+    """fem3d Q1 p=4 L=6 (BASELINE configs[3] at full size: 262 144 nodes), on one GPU; the
+    default start is infeasible there, so the properties are probed from a lifted slack."""
+    prob = m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 6), prolongator=m.amg_ruge_stuben(max_coarse=300)), p=4.0)
+    prob.g[:, 1] = 1.0e4                       # s^(2/p) = 100 > |grad g|^2 <= 12 everywhere
+    _full_size_properties(prob, 1e-5)
+
+
+def test_config5_full_size_properties():
+    """spectral2d n=32 with the two-sided obstacle (BASELINE configs[4]: 1024 nodes, dense
+    1924 x 1924 Hessians on the fp64 matrix cores)."""
+    mg = m.amg(m.spectral2d(n=32))
+    nn = mg.geometry.w.size
+    Q = m.intersect(mg, m.convex_Euclidian_power(mg, idx=(2, 3, 4), p_grid=np.full(nn, 1.5)),
+                    m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[1.0], [-1.0]]), b=lambda x: np.array([0.1, 1.0])))
+    prob = m.assemble(mg, Q=Q, f_grid=np.tile([2.0, 0, 0, 0.5], (nn, 1)), g_grid=np.tile([0.0, 10.0], (nn, 1)))
+    _full_size_properties(prob, 1e-7)
+
+
 def test_config2_size_properties_and_determinism():
     """fem2d_P2 p=1.5 L=7 (BASELINE configs[1]): size-independent properties instead of an oracle run."""
     prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 7)), p=1.5)
