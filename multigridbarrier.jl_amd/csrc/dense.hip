@@ -218,39 +218,52 @@ __global__ __launch_bounds__(256) void dense_weight_kernel(int klo, int khi, int
 constexpr int GT = 64;     // tile edge
 constexpr int GK = 16;     // K tile
 
+template <bool HASV>
 __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(int M, int N, int K, const double* __restrict__ A,
                                                             int64_t lda, const double* __restrict__ v,
                                                             const double* __restrict__ B, int64_t ldb,
                                                             double* __restrict__ C, int64_t ldc, int accumulate,
                                                             int symmetric) {
-    __shared__ double As[2][GK][GT];
-    __shared__ double Bs[2][GK][GT];
+    __shared__ double As[2][GK][GT + 1];      // odd row stride: the k-fastest stores below are conflict-free
+    __shared__ double Bs[2][GK][GT + 1];
     const int bi = blockIdx.x, bj = blockIdx.y;
     if (symmetric && bi > bj) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int i0 = bi * GT, j0 = bj * GT;
-    const int lc = tid >> 2, lk = (tid & 3) * 4;
-    const bool a_in = (i0 + lc) < M, b_in = (j0 + lc) < N;
-    const double* Ap = A + lda * (int64_t)(i0 + lc) + lk;
-    const double* Bp = B + ldb * (int64_t)(j0 + lc) + lk;
-    double ra[4], rb[4];
+    // Staging map: 16 consecutive lanes read 16 consecutive k of one column (one full 128-byte
+    // line), each thread covers 4 columns 16 apart; a wave-level load touches 4 lines, not 16.
+    // Branch-free: addresses are clamped into range so every load is unconditional and nothing
+    // consumes a loaded value before the LDS store (a guarded load or an early use makes the
+    // compiler drain vmcnt inside the prefetch); masks and the diag(v) scaling apply at store time.
+    static_assert(GK == 16 && GT == 64, "staging map assumes a 16 x 64 operand tile");
+    const int lk = tid & 15, lc = tid >> 4;
+    const double* Ap[4];
+    const double* Bp[4];
+    bool a_in[4], b_in[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a_in[q] = i0 + lc + 16 * q < M;
+        b_in[q] = j0 + lc + 16 * q < N;
+        Ap[q] = A + lda * (int64_t)min(i0 + lc + 16 * q, M - 1);
+        Bp[q] = B + ldb * (int64_t)min(j0 + lc + 16 * q, N - 1);
+    }
+    double ra[4], rb[4], rv = 1.0;
     auto gload = [&](int k0) {
+        const int kc = min(k0 + lk, K - 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int kk = k0 + lk + q;
-            const bool kin = kk < K;
-            ra[q] = (kin && a_in) ? Ap[k0 + q] : 0.0;
-            double bv = (kin && b_in) ? Bp[k0 + q] : 0.0;
-            if (v != nullptr && kin) bv *= v[kk];
-            rb[q] = bv;
+            ra[q] = Ap[q][kc];
+            rb[q] = Bp[q][kc];
         }
+        if (HASV) rv = v[kc];
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, int k0) {
+        const bool kin = k0 + lk < K;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            As[buf][lk + q][lc] = ra[q];
-            Bs[buf][lk + q][lc] = rb[q];
+            As[buf][lk][lc + 16 * q] = (kin && a_in[q]) ? ra[q] : 0.0;
+            Bs[buf][lk][lc + 16 * q] = (kin && b_in[q]) ? (HASV ? rb[q] * rv : rb[q]) : 0.0;
         }
     };
     double4_t acc[2][2];
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(int M, int N, int K,
         for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
     const int nkt = (K + GK - 1) / GK;
     gload(0);
-    sstore(0);
+    sstore(0, 0);
     __syncthreads();
     const int fr = lane & 15, fk = lane >> 4;
     for (int kt = 0; kt < nkt; ++kt) {
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(int M, int N, int K,
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nkt) sstore(cur ^ 1);
+        if (kt + 1 < nkt) sstore(cur ^ 1, (kt + 1) * GK);
         __syncthreads();
     }
     // D'[jj][ii] with jj = (lane>>4) + 4*reg (row of the swapped product = column of C),
@@ -333,8 +346,13 @@ void launch_dense_gemm_tn(int M, int N, int K, const double* A, int64_t lda, con
     if (M == 0 || N == 0) return;
     if (symmetric && M != N) throw InvalidArgument("dense_gemm_tn: symmetric product must be square");
     const dim3 grid((unsigned)((M + GT - 1) / GT), (unsigned)((N + GT - 1) / GT));
-    hipLaunchKernelGGL(dense_gemm_tn_kernel, grid, dim3(256), 0, st, M, N, K, A, lda, v, B, ldb, C, ldc,
-                       accumulate ? 1 : 0, symmetric ? 1 : 0);
+    if (K == 0) throw InvalidArgument("dense_gemm_tn: empty contraction");
+    if (v != nullptr)
+        hipLaunchKernelGGL(dense_gemm_tn_kernel<true>, grid, dim3(256), 0, st, M, N, K, A, lda, v, B, ldb, C, ldc,
+                           accumulate ? 1 : 0, symmetric ? 1 : 0);
+    else
+        hipLaunchKernelGGL(dense_gemm_tn_kernel<false>, grid, dim3(256), 0, st, M, N, K, A, lda, v, B, ldb, C, ldc,
+                           accumulate ? 1 : 0, symmetric ? 1 : 0);
     MGB_HIP_CHECK(hipGetLastError());
 }
 
