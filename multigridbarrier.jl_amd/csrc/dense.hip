@@ -248,22 +248,24 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(int M, int N, int K,
         Ap[q] = A + lda * (int64_t)min(i0 + lc + 16 * q, M - 1);
         Bp[q] = B + ldb * (int64_t)min(j0 + lc + 16 * q, N - 1);
     }
-    double ra[4], rb[4], rv = 1.0;
-    auto gload = [&](int k0) {
+    // Register ring of three K tiles in flight ahead of the one being multiplied (one tile of
+    // look-ahead is 0.4 us of MFMA work, an L2/MALL round trip is several times that).
+    double ra[3][4], rb[3][4], rv[3] = {1.0, 1.0, 1.0};
+    auto gload = [&](int k0, double (&xa)[4], double (&xb)[4], double& xv) {
         const int kc = min(k0 + lk, K - 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            ra[q] = Ap[q][kc];
-            rb[q] = Bp[q][kc];
+            xa[q] = Ap[q][kc];
+            xb[q] = Bp[q][kc];
         }
-        if (HASV) rv = v[kc];
+        if (HASV) xv = v[kc];
     };
-    auto sstore = [&](int buf, int k0) {
+    auto sstore = [&](int buf, int k0, const double (&xa)[4], const double (&xb)[4], double xv) {
         const bool kin = k0 + lk < K;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            As[buf][lk][lc + 16 * q] = (kin && a_in[q]) ? ra[q] : 0.0;
-            Bs[buf][lk][lc + 16 * q] = (kin && b_in[q]) ? (HASV ? rb[q] * rv : rb[q]) : 0.0;
+            As[buf][lk][lc + 16 * q] = (kin && a_in[q]) ? xa[q] : 0.0;
+            Bs[buf][lk][lc + 16 * q] = (kin && b_in[q]) ? (HASV ? xb[q] * xv : xb[q]) : 0.0;
         }
     };
     double4_t acc[2][2];
@@ -272,13 +274,8 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(int M, int N, int K,
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
     const int nkt = (K + GK - 1) / GK;
-    gload(0);
-    sstore(0, 0);
-    __syncthreads();
     const int fr = lane & 15, fk = lane >> 4;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) gload((kt + 1) * GK);
+    auto multiply = [&](int cur) {
 #pragma unroll
         for (int ks = 0; ks < GK / 4; ++ks) {
             const double a0 = As[cur][ks * 4 + fk][wm * 32 + fr];
@@ -291,8 +288,25 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(int M, int N, int K,
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nkt) sstore(cur ^ 1, (kt + 1) * GK);
-        __syncthreads();
+    };
+    gload(0, ra[0], rb[0], rv[0]);
+    gload(GK, ra[1], rb[1], rv[1]);
+    gload(2 * GK, ra[2], rb[2], rv[2]);
+    sstore(0, 0, ra[0], rb[0], rv[0]);
+    __syncthreads();
+    // tile t is in LDS buffer t & 1; tiles t+1, t+2 wait in ring slots (t+1)%3, (t+2)%3; slot t%3
+    // is free and receives tile t+3.  Unrolled by 3: the ring slots are compile-time registers.
+    for (int kt = 0; kt < nkt; kt += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = kt + u;
+            if (t < nkt) {
+                gload((t + 3) * GK, ra[u], rb[u], rv[u]);
+                multiply(t & 1);
+                if (t + 1 < nkt) sstore((t + 1) & 1, (t + 1) * GK, ra[(u + 1) % 3], rb[(u + 1) % 3], rv[(u + 1) % 3]);
+                __syncthreads();
+            }
+        }
     }
     // D'[jj][ii] with jj = (lane>>4) + 4*reg (row of the swapped product = column of C),
     // ii = lane&15 (column of the swapped product = row of C)
