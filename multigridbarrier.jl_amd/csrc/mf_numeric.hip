@@ -106,7 +106,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                                 const int32_t* __restrict__ children, const int32_t* __restrict__ rel,
                                 const int32_t* __restrict__ a_src, const int32_t* __restrict__ a_dst,
                                 const double* __restrict__ Hval, double* __restrict__ arena,
-                                int32_t* __restrict__ status, int exp_mask) {
+                                int32_t* __restrict__ status) {
     extern __shared__ double W[];
     const FrontDev F = fr[first + blockIdx.x];
     double* Fg = arena + F.F_off;
@@ -131,7 +131,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     __shared__ int32_t cM[CHILD_CHUNK], cB[CHILD_CHUNK];
     __shared__ int32_t crl[128];               // relative indices of one larger child (b <= m <= 128)
     __shared__ double prinv[32];               // reciprocal pivots of the current panel
-    for (int cbase = 0; cbase < ((exp_mask & 1) ? 0 : F.nchild); cbase += CHILD_CHUNK) {
+    for (int cbase = 0; cbase < F.nchild; cbase += CHILD_CHUNK) {
         const int nc = min(CHILD_CHUNK, F.nchild - cbase);
         __syncthreads();
         if (tid < nc) {
@@ -1221,7 +1221,6 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 hipLaunchKernelGGL(mf_factor_tiny, dim3((L.count + 15) / 16), dim3(256), 0, st, d_fronts.p, L.first,
                                    L.count, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
             } else if (L.cls) {
-                static const int exp_mask = [] { const char* e = getenv("MGBHIP_EXP"); return e ? atoi(e) : 0; }();
                 static const int nbt_mid = [] { const char* e = getenv("MGBHIP_NBT"); return e ? atoi(e) : 8; }();
                 const int threads = L.cls <= 16 ? 64 : (L.cls <= 32 ? 128 : 256);
                 const int nbt = L.cls <= 16 ? 8 : std::min(nbt_mid, 16);    // 32-column LDS panels do not fit beside a 128 x 128 front
@@ -1229,13 +1228,13 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 const size_t lds = (size_t)(L.cls * L.cls + nbt_alloc * L.cls) * sizeof(double);    // front + scaled panel
                 if (nbt <= 8)
                     hipLaunchKernelGGL(mf_factor_small<8>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p, exp_mask);
+                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
                 else if (nbt <= 16)
                     hipLaunchKernelGGL(mf_factor_small<16>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p, exp_mask);
+                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
                 else
                     hipLaunchKernelGGL(mf_factor_small<32>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p, exp_mask);
+                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
             } else {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
                 hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,

@@ -1,5 +1,5 @@
 """Factor/solve microbenchmark at the fine level: python tools/gpu_solver_bench.py L p reps
-(MGBHIP_EXP bit mask switches parts of the small-front kernel off: 1 children, 2 factor, 4 write-out, 8 A scatter)."""
+."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,5 +23,5 @@ for _ in range(reps):
         pass
 for st in ('factor', 'trisolve'):
     ms, cnt = P.stage_ms(st)
-    print(f"EXP={os.environ.get('MGBHIP_EXP','0')} {st:9s} {1e3*ms/max(cnt,1):9.1f} us", flush=True)
+    print(f"{st:9s} {1e3*ms/max(cnt,1):9.1f} us", flush=True)
 D.close()
