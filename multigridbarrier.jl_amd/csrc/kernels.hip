@@ -497,6 +497,39 @@ __global__ __launch_bounds__(256) void csr_matvec_wave_kernel(int64_t rows, cons
     if (lane == 0) y[i] = ADD ? y[i] + s : s;
 }
 
+// Very long rows (restriction onto a handful of coarse unknowns: every row of R' spans a large
+// part of the mesh): a workgroup per (row, 4096-entry chunk), partial sums to scratch, then a
+// fixed-order sum over the chunks -- deterministic, and the whole GPU works on a 3-row matvec.
+constexpr int CHUNK = 4096;
+__global__ __launch_bounds__(256) void csr_matvec_chunk_kernel(const int32_t* __restrict__ ptr,
+                                                               const int32_t* __restrict__ col,
+                                                               const double* __restrict__ val,
+                                                               const double* __restrict__ x,
+                                                               double* __restrict__ partial, int nchunk) {
+    __shared__ double red[256];
+    const int row = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int32_t q0 = ptr[row] + ch * CHUNK;
+    const int32_t q1 = min(ptr[row + 1], q0 + CHUNK);
+    double s = 0.0;
+    for (int32_t q = q0 + tid; q < q1; q += 256) s += val[q] * x[col[q]];
+    red[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) partial[(int64_t)row * nchunk + ch] = red[0];
+}
+
+__global__ __launch_bounds__(256) void csr_matvec_chunk_sum_kernel(int64_t rows, const double* __restrict__ partial,
+                                                                   int nchunk, double* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += partial[i * nchunk + c];
+    y[i] = s;
+}
+
 // zfull = z0 + R*s  (src/convex.jl:156): one thread per broken row, so the element kernels
 // read their local values with independent coalesced loads instead of a dependent
 // rowptr -> col/val -> s chain per tile.
@@ -787,6 +820,18 @@ void launch_csr_matvec(int64_t rows, const int32_t* ptr, const int32_t* col, con
         if (add) hipLaunchKernelGGL(csr_matvec_row_kernel<true>, grid, dim3(256), 0, st, rows, ptr, col, val, x, y);
         else hipLaunchKernelGGL(csr_matvec_row_kernel<false>, grid, dim3(256), 0, st, rows, ptr, col, val, x, y);
     }
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+int csr_chunks(int64_t max_row_len) { return (int)((max_row_len + CHUNK - 1) / CHUNK); }
+
+void launch_csr_matvec_chunked(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val,
+                               const double* x, double* y, double* scratch, int nchunk, hipStream_t st) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(csr_matvec_chunk_kernel, dim3((unsigned)nchunk, (unsigned)rows), dim3(256), 0, st, ptr, col, val, x,
+                       scratch, nchunk);
+    hipLaunchKernelGGL(csr_matvec_chunk_sum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows, scratch,
+                       nchunk, y);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

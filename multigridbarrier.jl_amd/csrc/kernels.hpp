@@ -63,6 +63,10 @@ int64_t reduce_scratch_doubles(int64_t n);
 // y[i] = sum_j A[i,j] x[j]  (CSR, deterministic; wave-per-row when rows are long)
 void launch_csr_matvec(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val,
                        const double* x, double* y, bool add, bool long_rows, hipStream_t st);
+// rows of more than ~8K entries: (row, chunk) workgroups + fixed-order sum; scratch holds rows*nchunk doubles
+int csr_chunks(int64_t max_row_len);
+void launch_csr_matvec_chunked(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val,
+                               const double* x, double* y, double* scratch, int nchunk, hipStream_t st);
 void launch_prolong(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val, const double* s,
                     const double* z0, double* zfull, hipStream_t st);
 // xn = x - s*n ; flag[0] |= any(xn != x)

@@ -48,6 +48,7 @@ static void upload_csr(const mgbhip_csr& R, Level& L, hipStream_t st) {
         }
     for (int64_t j = 0; j < R.cols; ++j) maxrow = std::max(maxrow, tp[j + 1] - tp[j]);
     L.T_long = maxrow > 64;
+    L.T_chunks = (maxrow >= 8192 && R.cols <= 4096) ? csr_chunks(maxrow) : 0;
     int32_t maxr = 0;
     for (int64_t i = 0; i < R.rows; ++i) maxr = std::max(maxr, L.hRptr[i + 1] - L.hRptr[i]);
     L.R_long = maxr > 64;
@@ -211,6 +212,11 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     P->d_nodeF.alloc((size_t)P->n);
     P->d_x.alloc(mmax); P->d_g.alloc(mmax); P->d_nv.alloc(mmax); P->d_xn.alloc(mmax);
     P->d_gn.alloc(mmax); P->d_tmp.alloc(mmax);
+    {
+        size_t tch = 1;
+        for (auto& L : P->levels) tch = std::max(tch, (size_t)L.T_chunks * (size_t)L.m);
+        P->d_tchunk.alloc(tch);
+    }
     P->d_flag.alloc(4);
     MGB_HIP_CHECK(hipStreamSynchronize(st));
     return P.release();
@@ -561,7 +567,10 @@ void mgbhip_problem::eval_f1(int level, const double* d_s, const double* d_zz, c
     }
     {
         StageScope sc(ctx->timers, "restrict");
-        launch_csr_matvec(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, false, L.T_long, st);
+        if (L.T_chunks > 0)
+            launch_csr_matvec_chunked(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, d_tchunk.p, L.T_chunks, st);
+        else
+            launch_csr_matvec(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, false, L.T_long, st);
     }
     cnt.f1++;
 }

@@ -33,6 +33,7 @@ struct Level {
     DevBuf<int32_t> Rptr, Rcol, Tptr, Tcol;
     DevBuf<double> Rval, Tval;
     bool T_long = false, R_long = false;
+    int32_t T_chunks = 0;                 // > 0: rows of R' are long enough for the chunked matvec
     // assembly plan for H = R' H_blk R (reference: BlockAssemblyPlan, src/BlockMatrices.jl:281-491)
     bool planned = false;
     bool selection = false;               // every row of R has at most one entry, equal to 1
@@ -72,7 +73,7 @@ struct mgbhip_problem {
     bool has_bw = false;
     std::vector<mgbhip::Level> levels;
     // workspace
-    mgbhip::DevBuf<double> d_z, d_z0, d_zfull, d_c, d_ret, d_hel, d_partials, d_scal, d_scratch, d_nodeF, d_nodeDz, d_dnDz, d_dnY;
+    mgbhip::DevBuf<double> d_z, d_z0, d_zfull, d_c, d_ret, d_hel, d_partials, d_scal, d_scratch, d_nodeF, d_nodeDz, d_dnDz, d_dnY, d_tchunk;
     mgbhip::DevBuf<double> d_x, d_g, d_nv, d_xn, d_gn, d_tmp, d_c0;
     mgbhip::DevBuf<int32_t> d_flag;
     mgbhip::Counters cnt;
