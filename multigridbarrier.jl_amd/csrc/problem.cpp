@@ -48,7 +48,7 @@ static void upload_csr(const mgbhip_csr& R, Level& L, hipStream_t st) {
         }
     for (int64_t j = 0; j < R.cols; ++j) maxrow = std::max(maxrow, tp[j + 1] - tp[j]);
     L.T_long = maxrow > 64;
-    L.T_chunks = (maxrow >= 8192 && R.cols <= 4096) ? csr_chunks(maxrow) : 0;
+    L.T_chunks = (maxrow >= 1024 && R.cols <= 16384) ? csr_chunks(maxrow) : 0;
     int32_t maxr = 0;
     for (int64_t i = 0; i < R.rows; ++i) maxr = std::max(maxr, L.hRptr[i + 1] - L.hRptr[i]);
     L.R_long = maxr > 64;
