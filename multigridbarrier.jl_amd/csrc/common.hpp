@@ -76,6 +76,23 @@ struct DevBuf {
     }
 };
 
+// Small pinned host block for scalar read-backs (a pageable destination sends every 8-byte
+// copy through the runtime's staging path).
+struct PinnedBuf {
+    double* d = nullptr;        // 16 doubles
+    int32_t* i = nullptr;       // 16 ints
+    PinnedBuf() {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 16 * sizeof(double) + 16 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
+            throw HipError("hipHostMalloc failed for the scalar read-back block");
+        d = static_cast<double*>(p);
+        i = reinterpret_cast<int32_t*>(d + 16);
+    }
+    ~PinnedBuf() { if (d) (void)hipHostFree(d); }
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+};
+
 // hipEvent-based per-stage device timers on the handle's stream (bench.py's roofline
 // numbers come from these; torch.cuda.Event would only see torch's own stream).
 struct StageTimers {

@@ -48,19 +48,17 @@ struct VecStats { double sumsq, bad; };
 VecStats vec_stats(mgbhip_problem* P, const double* d_v, int64_t len) {
     hipStream_t st = P->stream();
     launch_vec_stats(d_v, len, P->d_scratch.p, P->d_scal.p + 2, st);
-    double h[2];
-    MGB_HIP_CHECK(hipMemcpyAsync(h, P->d_scal.p + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     MGB_HIP_CHECK(hipStreamSynchronize(st));
-    return VecStats{h[0], h[1]};
+    return VecStats{P->pin.d[2], P->pin.d[3]};
 }
 
 double dev_dot(mgbhip_problem* P, const double* a, const double* b, int64_t len) {
     hipStream_t st = P->stream();
     launch_dot(a, b, len, P->d_scratch.p, P->d_scal.p + 4, st);
-    double h;
-    MGB_HIP_CHECK(hipMemcpyAsync(&h, P->d_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
+    MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 4, P->d_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
     MGB_HIP_CHECK(hipStreamSynchronize(st));
-    return h;
+    return P->pin.d[4];
 }
 
 struct NewtonCtx {
@@ -76,14 +74,23 @@ struct NewtonCtx {
 
 // One line-search trial shared by both searches: evaluates F0/F1 at xn (already formed in
 // P->d_xn), rejects non-finite values like the reference's `error(...)` + catch protocol.
-bool trial_values(NewtonCtx& C, double& ynext, double& gnorm_next) {
+// F0, F1 and the gradient statistics are launched back to back and read with ONE
+// synchronisation (value, sum of squares, non-finite count, and the step kernel's "moved" flag):
+// evaluating F1 at a point F0 rejects only produces NaN/Inf that nobody reads.
+bool trial_values(NewtonCtx& C, double& ynext, double& gnorm_next, int32_t* moved = nullptr) {
     mgbhip_problem* P = C.P;
-    ynext = C.F0(P->d_xn.p);
-    if (!std::isfinite(ynext)) return false;
+    hipStream_t st = P->stream();
+    P->eval_f0_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c);
     C.F1(P->d_xn.p, P->d_gn.p);
-    VecStats gs = vec_stats(P, P->d_gn.p, C.m);
-    if (gs.bad != 0.0 || !std::isfinite(gs.sumsq)) return false;
-    gnorm_next = std::sqrt(gs.sumsq);
+    launch_vec_stats(P->d_gn.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st);
+    MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d, P->d_scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    MGB_HIP_CHECK(hipMemcpyAsync(P->pin.i, P->d_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (moved) *moved = P->pin.i[0];
+    ynext = P->pin.d[0];
+    if (!std::isfinite(ynext)) return false;
+    if (P->pin.d[3] != 0.0 || !std::isfinite(P->pin.d[2])) return false;
+    gnorm_next = std::sqrt(P->pin.d[2]);
     return true;
 }
 
@@ -101,10 +108,8 @@ bool linesearch_backtracking(NewtonCtx& C, const mgbhip_options& opt, double y, 
         launch_step(P->d_x.p, P->d_nv.p, s, P->d_xn.p, C.m, P->d_flag.p, st);
         P->touch();
         double yn, gn;
-        if (trial_values(C, yn, gn)) {
-            int32_t moved = 0;
-            P->d_flag.download(&moved, 1, st);
-            MGB_HIP_CHECK(hipStreamSynchronize(st));
+        int32_t moved = 0;
+        if (trial_values(C, yn, gn, &moved)) {
             have = true;
             ynext = yn;
             gnorm_next = gn;
@@ -188,7 +193,13 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         auto t0 = std::chrono::steady_clock::now();
         P->factor(C.level);
         P->trisolve(C.level, P->d_g.p, P->d_nv.p);
-        const int fstatus = L.solver.status(st);
+        // pivot flag, direction statistics and lambda^2 = <g, n> in one round trip
+        launch_vec_stats(P->d_nv.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st);
+        launch_dot(P->d_g.p, P->d_nv.p, C.m, P->d_scratch.p, P->d_scal.p + 4, st);
+        MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+        L.solver.status_async(P->pin.i + 1, st);
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
+        const int fstatus = MfSolver::status_from(P->pin.i[1]);
         P->cnt.solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (fstatus != MGBHIP_OK) {
             DBG("newton[lev %d] k=%d: Cholesky met a non-positive pivot (y=%.17g |g|=%.6e)\n", C.level, k, y, gnorm);
@@ -197,9 +208,8 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
             converged = false;
             break;
         }
-        VecStats ns = vec_stats(P, P->d_nv.p, C.m);
-        if (ns.bad != 0.0 || !std::isfinite(ns.sumsq)) throw InvalidArgument("newton: Newton direction has non-finite entries");
-        const double inc = dev_dot(P, P->d_g.p, P->d_nv.p, C.m);
+        if (P->pin.d[3] != 0.0 || !std::isfinite(P->pin.d[2])) throw InvalidArgument("newton: Newton direction has non-finite entries");
+        const double inc = P->pin.d[4];
         DBG("newton[lev %d] k=%d y=%.17g |g|=%.6e lambda^2=%.6e\n", C.level, k, y, gnorm, inc);
         if (inc <= 0) {
             converged = std::fabs(inc) <= EPS * std::fmax(std::fabs(y), 1.0);   // src/newton.jl:257-271

@@ -1319,6 +1319,10 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
     if (timers) timers->end();
 }
 
+void MfSolver::status_async(int32_t* h_dst, hipStream_t st) const {
+    MGB_HIP_CHECK(hipMemcpyAsync(h_dst, d_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+}
+
 int MfSolver::status(hipStream_t st) {
     int32_t h = 0;
     d_status.download(&h, 1, st);

@@ -32,6 +32,9 @@ class MfSolver {
     // x = A^{-1} b (device vectors of length n; x may alias b)
     void solve(const double* d_b, double* d_x, hipStream_t st, StageTimers* timers);
     int status(hipStream_t st);     // synchronises; MGBHIP_OK or MGBHIP_ERR_NOT_SPD
+    // enqueue the copy of the flag only (pinned destination); interpret it after the caller's sync
+    void status_async(int32_t* h_dst, hipStream_t st) const;
+    static int status_from(int32_t flag) { return flag ? MGBHIP_ERR_NOT_SPD : MGBHIP_OK; }
     bool analyzed = false;
 
    private:

@@ -542,19 +542,21 @@ ElemParams mgbhip_problem::base_params(int level, const double* d_s, const doubl
     return E;
 }
 
+void mgbhip_problem::eval_f0_launch(int level, const double* d_s, const double* d_zz, const double* d_cc) {
+    hipStream_t st = stream();
+    StageScope sc(ctx->timers, level + 1 == (int)levels.size() ? "f0" : "f0_coarse");
+    ElemParams E = base_params(level, d_s, d_zz, d_cc);
+    launch_elem(E, MODE_F0, st);
+    launch_reduce_partials(d_partials.p, elem_grid(p, N), d_scal.p, st);
+    cnt.f0++;
+}
+
 double mgbhip_problem::eval_f0(int level, const double* d_s, const double* d_zz, const double* d_cc) {
     hipStream_t st = stream();
-    {
-        StageScope sc(ctx->timers, level + 1 == (int)levels.size() ? "f0" : "f0_coarse");
-        ElemParams E = base_params(level, d_s, d_zz, d_cc);
-        launch_elem(E, MODE_F0, st);
-        launch_reduce_partials(d_partials.p, elem_grid(p, N), d_scal.p, st);
-    }
-    double v = 0;
-    d_scal.download(&v, 1, st);
+    eval_f0_launch(level, d_s, d_zz, d_cc);
+    MGB_HIP_CHECK(hipMemcpyAsync(pin.d, d_scal.p, sizeof(double), hipMemcpyDeviceToHost, st));
     MGB_HIP_CHECK(hipStreamSynchronize(st));
-    cnt.f0++;
-    return v;
+    return pin.d[0];
 }
 
 void mgbhip_problem::eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout) {

@@ -76,6 +76,7 @@ struct mgbhip_problem {
     mgbhip::DevBuf<double> d_z, d_z0, d_zfull, d_c, d_ret, d_hel, d_partials, d_scal, d_scratch, d_nodeF, d_nodeDz, d_dnDz, d_dnY, d_tchunk;
     mgbhip::DevBuf<double> d_x, d_g, d_nv, d_xn, d_gn, d_tmp, d_c0;
     mgbhip::DevBuf<int32_t> d_flag;
+    mgbhip::PinnedBuf pin;                 // scalar read-backs of the Newton loop
     mgbhip::Counters cnt;
     // z0 + R*s is cached in d_zfull across the f0/f1/f2 calls at one point: the key is the
     // (level, s, z) pointers plus a stamp every writer of those vectors bumps (touch()).
@@ -91,6 +92,8 @@ struct mgbhip_problem {
     void ensure_plan(int level);
     void ensure_plan_dense(int level);
     double eval_f0(int level, const double* d_s, const double* d_zz, const double* d_cc);
+    // kernels only: the value lands in d_scal[0]; the caller batches the read-back
+    void eval_f0_launch(int level, const double* d_s, const double* d_zz, const double* d_cc);
     void eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
     void eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc);
     // returns MGBHIP_OK or MGBHIP_ERR_NOT_SPD; x = H^{-1} g on the device
