@@ -128,4 +128,9 @@ def find_boundary(geom: Geometry):
         return fem2d_p2.find_boundary(geom)
     if isinstance(disc, tensorfem.TensorFEM):
         return tensorfem.find_boundary(geom)
+    if isinstance(disc, spectral.SPECTRAL1D):     # informational only (reference: src/spectral1d.jl:119-130)
+        return [(0, 0), (disc.n - 1, 0)]
+    if isinstance(disc, spectral.SPECTRAL2D):     # perimeter of the tensor grid (src/spectral2d.jl:52-69), 0-based
+        n = disc.n
+        return [(j * n + i, 0) for j in range(n) for i in range(n) if i in (0, n - 1) or j in (0, n - 1)]
     raise TypeError(f"find_boundary: unsupported discretization {type(disc).__name__}")

@@ -85,3 +85,50 @@ def test_convex_validation():
         m.assemble(mg, Q=m.convex_Euclidian_power(mg, idx=(2, 3, 4)))        # indexes row 4 of a 3-row D
     Q = m.intersect(mg, m.convex_Euclidian_power(mg, idx=(2, 3)), m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[1.0], [-1.0]]), b=lambda x: np.array([2.0, 2.0])))
     assert len(Q.pieces) == 2 and Q.select is None
+
+
+def test_per_subspace_hierarchies_fem1d_reference_shapes():
+    # test/test_mixed_bc.jl:79-95: :dirichlet bridges interior P1 (7) and :full all-corners P1 (9) to the 16 broken nodes
+    mg = m.amg(m.fem1d(nodes=np.linspace(-1.0, 1.0, 9)))
+    Kd, Kf = len(mg.R["dirichlet"]) - 2, len(mg.R["full"]) - 2
+    assert mg.R["dirichlet"][Kd].shape == (16, 7)
+    assert mg.R["full"][Kf].shape == (16, 9)
+
+
+@pytest.mark.parametrize("geom", ["fem2d_P2", "fem3d"])
+def test_subspaces_are_stretched_to_a_common_depth(geom):
+    # test/test_mixed_bc.jl:110-137
+    g = m.subdivide(m.fem2d_P2(), 2) if geom == "fem2d_P2" else m.subdivide(m.fem3d(k=1), 2)
+    mg = m.amg(g)
+    L = len(mg.R["dirichlet"])
+    assert L == len(mg.R["full"])
+    assert mg.R["dirichlet"][L - 1].shape[0] == mg.R["full"][L - 1].shape[0]
+
+
+def test_named_dirichlet_subspaces_reference_shapes():
+    # test/test_mixed_bc.jl:147-201: per-component Dirichlet boundaries through named subspaces
+    geom = m.subdivide(m.fem2d_P2(), 2)
+    b = m.find_boundary(geom)
+    x = geom.xflat
+    keep_u = [(v, e) for (v, e) in b if abs(x[v + 7 * e, 0] + 1.0) <= 1e-10]      # the edge x = -1 only
+    assert 0 < len(keep_u) < len(b)
+    mg = m.amg(geom, dirichlet_nodes={"dir_u": keep_u, "dir_v": b})
+    for key in ("dir_u", "dir_v", "full", "uniform"):
+        assert key in mg.R
+    assert len(mg.R["dir_u"]) == len(mg.R["dir_v"])
+    iv = mg.R["dir_v"][-1].shape[1]
+    iu = mg.R["dir_u"][-1].shape[1]
+    assert iv < iu                                   # fewer zeroed nodes -> more free DOFs
+    for bad in ("full", "uniform"):
+        with pytest.raises(ValueError):
+            m.amg(geom, dirichlet_nodes={bad: b})
+    # default still provides :dirichlet on the whole boundary
+    assert m.amg(geom).R["dirichlet"][-1].shape == mg.R["dir_v"][-1].shape
+
+
+def test_find_boundary_counts():
+    # test/test_mixed_bc.jl:66-68 and the fem3d k=2 single-hex count (:60-62)
+    assert m.find_boundary(m.spectral1d(n=5)) == [(0, 0), (4, 0)]          # 0-based twin of [(1, 1), (5, 1)]
+    assert len(m.find_boundary(m.spectral2d(n=4))) == 4 * 4 - (4 - 2) ** 2
+    g = m.fem3d(k=2)
+    assert len(m.find_boundary(g)) == g.x.shape[0] * g.x.shape[1] - 1
