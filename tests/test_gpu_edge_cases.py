@@ -144,3 +144,46 @@ def test_handles_are_independent_and_reusable():
     sa.device.close()
     assert np.array_equal(again["z"], sa.z)
     assert np.abs(sb.z - O.mgb_solve(pb)["z"]).max() < 1e-8
+
+
+def test_intersect_of_linear_cones_with_phase1_single_state():
+    # test/test_cuda.jl:58-79: minimise int u subject to 1 <= u <= 5 from the infeasible start u = 0
+    # (one state variable, intersect of two linear cones, phase-I slack path)
+    mg = m.amg(m.fem2d_P2())
+    Qa = m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[1.0]]), b=lambda x: np.array([-1.0]))
+    Qb = m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[-1.0]]), b=lambda x: np.array([5.0]))
+    prob = m.assemble(mg, state_variables=[("u", "full")], D=[("u", "id")], f=lambda x: np.array([1.0]),
+                      g=lambda x: np.array([0.0]), Q=m.intersect(mg, Qa, Qb))
+    sol = m.mgb_solve(prob)
+    so = O.mgb_solve(prob)
+    assert sol.SOL_feasibility is not None
+    assert np.abs(sol.z - so["z"]).max() < 1e-8
+    assert np.abs(sol.z - 1.0).max() < 1e-5
+
+
+def test_explicit_stream_worker_thread_and_recovery_after_a_failed_solve():
+    # test/test_cuda.jl:118-139: the handle is bound to the caller's stream, works off the main
+    # thread, and a throwing solve leaves nothing stale behind
+    import ctypes
+    import threading
+    prob = m.assemble(m.amg(m.fem2d_P2()), p=1.5)
+    ref = O.mgb_solve(prob)["z"]
+    hip = ctypes.CDLL("libamdhip64.so")                # the runtime libmgbhip itself is linked against
+    stream = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+    try:
+        sol_stream = m.mgb_solve(prob, stream=stream.value)
+        assert np.abs(sol_stream.z - ref).max() < 1e-8
+    finally:
+        hip.hipStreamDestroy(stream)
+    box = {}
+    t = threading.Thread(target=lambda: box.setdefault("sol", m.mgb_solve(prob)))
+    t.start()
+    t.join()
+    assert np.abs(box["sol"].z - ref).max() < 1e-8
+    mgd = m.amg(m.fem1d(nodes=np.linspace(-1.0, 1.0, 9)))
+    Qd = m.convex_linear(mgd, idx=(1, 3), A=lambda x: np.array([[1.0, 0.0]]), b=lambda x: np.array([2.0]))
+    degenerate = m.assemble(mgd, Q=Qd)                 # slack unconstrained: must fail
+    with pytest.raises(Exception):
+        m.mgb_solve(degenerate)
+    assert np.abs(m.mgb_solve(prob).z - ref).max() < 1e-8
