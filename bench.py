@@ -88,11 +88,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # MGB_BENCH_REHEARSAL=1 (development only): all ranks share GPU 0 and talk over gloo, so that the
+    # multi-rank control flow can be exercised on a one-GPU box; the driver's runs use RCCL.
+    rehearsal = os.environ.get("MGB_BENCH_REHEARSAL", "0") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
 
     def barrier():
         if dist is not None:
@@ -111,7 +118,7 @@ def main():
         prob = build_problem(args.L, args.p, rs_kwargs)
         t_setup = time.perf_counter() - t0
         t0 = time.perf_counter()
-        D = DeviceMGBProblem(prob, device_id=local_rank)
+        D = DeviceMGBProblem(prob, device_id=dev_index)
         t_upload = time.perf_counter() - t0
         try:
             for _ in range(max(args.warmup, 1) if used is None else args.warmup):
@@ -142,7 +149,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     from mgb_amd.replicas import aggregate
-    elapsed_max, its_all = aggregate(elapsed, its_total, dist, device="cuda")
+    elapsed_max, its_all = aggregate(elapsed, its_total, dist, device="cpu" if rehearsal else "cuda")
 
     # ---- roofline of the dominant HBM kernel: fused element Hessian (f2), fine level ----
     # One more solve of the same workload, outside the timed region, with the library's hipEvent
