@@ -56,10 +56,10 @@ struct MfPlan {
 };
 
 struct MfOptions {
-    int32_t leaf_size = 32;
+    int32_t leaf_size = 24;       // measured best on MI355X (fem2d_P2 L=7..9); the optimum is flat between 16 and 32
     int32_t max_peel_rounds = 4;
     int32_t peel_max_degree = 48;
-    double sep_weight = 1.0;      // separator-size penalty in the bisection score
+    double sep_weight = 1.5;      // separator-size penalty in the bisection score
     int32_t merge_max_m = 0;      // relaxed amalgamation: merge a child into its parent while m stays <= this
 };
 
