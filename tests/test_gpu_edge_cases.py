@@ -187,3 +187,31 @@ def test_explicit_stream_worker_thread_and_recovery_after_a_failed_solve():
     with pytest.raises(Exception):
         m.mgb_solve(degenerate)
     assert np.abs(m.mgb_solve(prob).z - ref).max() < 1e-8
+
+
+def test_compiled_maxima_3d_parabolic_phase1():
+    """The largest descriptor the build accepts: 3-D parabolic step = 3 states + phase-I slack
+    (nu = 4 = MAX_NU), (dim + 3) + 1 + 3 = 10 operator rows (MAX_ND), index lists of 4 (MAX_IDX)."""
+    mg = m.amg(m.subdivide(m.fem3d(k=1), 2))
+    kw = dict(h=0.5, t1=0.5, p=1.5)
+    sol = m.parabolic_solve(mg, **kw)
+    so = m.parabolic_solve(mg, solver=O.mgb_solve, **kw)
+    assert all(s.SOL_feasibility is not None for s in sol.steps)
+    assert np.abs(np.stack(sol.u) - np.stack(so.u)).max() < 1e-6
+
+
+def test_four_piece_intersection_max_pieces():
+    """MAX_PIECES = 4: power cone intersected with three linear cones (box on u, sign of the slack)."""
+    mg = m.amg(m.subdivide(m.fem2d_P2(), 2))
+    n = mg.geometry.w.size
+    one = lambda a, b: m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[a]]), b=lambda x: np.array([b]))
+    Q = m.intersect(mg, m.convex_Euclidian_power(mg, idx=(2, 3, 4), p_grid=np.full(n, 1.5)),
+                    one(1.0, 0.5), one(-1.0, 3.0),
+                    m.convex_linear(mg, idx=(4,), A=lambda x: np.array([[1.0]]), b=lambda x: np.array([0.0])))
+    prob = m.assemble(mg, Q=Q)
+    sol = m.mgb_solve(prob)
+    so = O.mgb_solve(prob)
+    assert np.abs(sol.z - so["z"]).max() < 1e-7
+    with pytest.raises(ValueError):                       # a fifth piece exceeds this build
+        Q5 = m.intersect(mg, Q, one(1.0, 9.0))
+        dev.DeviceMGBProblem(m.assemble(mg, Q=Q5))
