@@ -655,6 +655,70 @@ __global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P)
     }
 }
 
+// Small coarse levels (m <= ACC_MAX_M unknowns): the projected element blocks overlap almost
+// everywhere (a coarse basis function spans a large part of the mesh), so a per-element slab is
+// m-independent gigabytes.  Instead every wave of a persistent grid owns a private dense m x m
+// accumulator (L2/MALL resident), adds the blocks of its elements in element order, and a second
+// kernel sums the accumulators in wave order: deterministic, and the slab round trip disappears.
+__global__ __launch_bounds__(256) void panel_accumulate_kernel(const PanelParams P, const int32_t* __restrict__ ecols,
+                                                               int32_t m, int32_t nwaves, double* __restrict__ copies) {
+    extern __shared__ double sh[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wave;
+    if (gw >= nwaves) return;
+    const int p = P.p, nu = P.nu;
+    double* tmp = sh + (size_t)wave * p * P.cmax;
+    double* Hp = copies + (int64_t)gw * m * m;
+    for (int64_t e = gw; e < P.N; e += nwaves) {
+        for (int a = 0; a < nu; ++a) {
+            const int32_t oa = P.ecol_ptr[e * nu + a], ca = P.ecol_ptr[e * nu + a + 1] - oa;
+            const double* pa = P.panels + (int64_t)p * oa;
+            for (int b = a; b < nu; ++b) {           // upper block triangle; (b, a) is its mirror
+                const int32_t ob = P.ecol_ptr[e * nu + b], cb = P.ecol_ptr[e * nu + b + 1] - ob;
+                const double* pb = P.panels + (int64_t)p * ob;
+                const int blk = a * nu - (a * (a - 1)) / 2 + (b - a);
+                const double* Hb = P.hel + ((int64_t)blk * P.N + e) * (int64_t)p * p;
+                for (int t = lane; t < p * cb; t += 64) {
+                    const int rr = t % p, ib = t / p;
+                    double acc = 0.0;
+                    for (int ss = 0; ss < p; ++ss) acc += Hb[rr + p * ss] * pb[ss + p * ib];
+                    tmp[t] = acc;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int t = lane; t < ca * cb; t += 64) {
+                    const int ia = t % ca, ib = t / ca;
+                    const int32_t gi = ecols[oa + ia], gj = ecols[ob + ib];
+                    // keep the upper triangle of H (row <= col); within the diagonal block pair
+                    // a == b the (ia, ib) and (ib, ia) entries are equal, one of them is enough
+                    if (a == b && gi > gj) continue;
+                    double acc = 0.0;
+                    for (int rr = 0; rr < p; ++rr) acc += pa[rr + p * ia] * tmp[rr + p * ib];
+                    const int64_t pos = gi <= gj ? (int64_t)gi + (int64_t)m * gj : (int64_t)gj + (int64_t)m * gi;
+                    Hp[pos] += acc;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+}
+
+// H[i, j] = H[j, i] = sum over the accumulators, in wave order (i <= j)
+__global__ __launch_bounds__(256) void accumulate_reduce_kernel(int32_t m, int32_t nwaves, const double* __restrict__ copies,
+                                                                double* __restrict__ H) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (int64_t)m * m) return;
+    const int i = (int)(q % m), j = (int)(q / m);
+    if (i > j) return;
+    double s = 0.0;
+    for (int w = 0; w < nwaves; ++w) s += copies[(int64_t)w * m * m + q];
+    H[(int64_t)i * m + j] = s;
+    H[(int64_t)j * m + i] = s;
+}
+
 template <int NY>
 void launch_elem_ny(const ElemParams& P, int mode, int lgG, dim3 grid, size_t lds, hipStream_t st) {
     switch (mode) {
@@ -871,6 +935,21 @@ void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cid
     else
         hipLaunchKernelGGL(gather_assemble_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, cptr,
                            cidx, slab, Hval);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t m, int32_t nwaves, double* copies,
+                             double* H, hipStream_t st) {
+    if (m == 0) return;
+    MGB_HIP_CHECK(hipMemsetAsync(copies, 0, sizeof(double) * (size_t)nwaves * m * m, st));
+    if (P.N > 0) {
+        const size_t lds = (size_t)4 * P.p * P.cmax * sizeof(double);
+        MGB_REQUIRE(lds <= 64 * 1024, "coarse-level panels too wide for the accumulation kernel");
+        hipLaunchKernelGGL(panel_accumulate_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), lds, st, P, ecols, m,
+                           nwaves, copies);
+    }
+    hipLaunchKernelGGL(accumulate_reduce_kernel, dim3((unsigned)(((int64_t)m * m + 255) / 256)), dim3(256), 0, st, m,
+                       nwaves, copies, H);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

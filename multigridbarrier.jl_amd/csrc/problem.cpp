@@ -5,10 +5,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
 using namespace mgbhip;
+
+static constexpr int64_t ACC_MAX_M = 384;   // general levels up to this size assemble a dense H from per-wave accumulators
 
 // ---------------------------------------------------------------------------------------------
 // problem construction
@@ -326,7 +330,31 @@ void mgbhip_problem::ensure_plan(int level) {
     const int64_t m = L.m;
     L.hHptr.assign(m + 1, 0);
     L.hHcol.clear();
-    if (selection) {
+    // Small general levels: dense H through per-wave accumulators (launch_panel_accumulate)
+    int32_t cmax_all = 1;
+    for (size_t q = 0; q + 1 < ecol_ptr.size(); ++q) cmax_all = std::max(cmax_all, ecol_ptr[q + 1] - ecol_ptr[q]);
+    {
+        // worth it only when the per-element slab (sum of ct^2 doubles, written and read back) is
+        // at least half the size of the accumulators (zeroed and summed; measured break-even, the
+        // long gather lists cost more than their bytes): wide coarse supports, i.e. 3-D
+        int64_t slab_est = 0;
+        for (int64_t e = 0; e < NE; ++e) {
+            const int64_t ct = ecol_ptr[(e + 1) * nu] - ecol_ptr[e * nu];
+            slab_est += ct * ct;
+        }
+        const int64_t waves = std::min<int64_t>(1024, std::max<int64_t>(4, (NE + 31) / 32));
+        L.acc = !selection && m > 0 && m <= ACC_MAX_M && (size_t)4 * pp * cmax_all * sizeof(double) <= 64 * 1024 &&
+                2 * slab_est > waves * m * m;
+        if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
+            fprintf(stderr, "[mgbhip] assembly plan level %d: m=%lld selection=%d cmax=%d slab=%lld doubles, accumulators=%lld -> %s\n", level,
+                    (long long)m, (int)selection, cmax_all, (long long)slab_est, (long long)(waves * m * m), L.acc ? "dense accumulate" : "slab + gather");
+    }
+    if (L.acc) {
+        L.hHcol.resize((size_t)(m * m));
+        for (int64_t i = 0; i <= m; ++i) L.hHptr[i] = (int32_t)(i * m);
+        for (int64_t i = 0; i < m; ++i)
+            for (int64_t j = 0; j < m; ++j) L.hHcol[i * m + j] = (int32_t)j;
+    } else if (selection) {
         // (row, col) pairs of every structural element contribution, bucketed by row
         std::vector<int32_t> rc(m + 1, 0);
         auto each_pair = [&](auto&& emit) {
@@ -403,7 +431,7 @@ void mgbhip_problem::ensure_plan(int level) {
         return (int32_t)(std::lower_bound(lo, hi, col) - L.hHcol.data());
     };
     std::vector<int64_t> eoff;
-    if (!selection) {
+    if (!selection && !L.acc) {
         eoff.assign((size_t)NE + 1, 0);
         for (int64_t e = 0; e < NE; ++e) {
             const int64_t ct = ecol_ptr[(e + 1) * nu] - ecol_ptr[e * nu];
@@ -444,7 +472,7 @@ void mgbhip_problem::ensure_plan(int level) {
             }
         }
     };
-    {
+    if (!L.acc) {
         std::vector<int32_t> ccount(L.nnz + 1, 0);
         for_each([&](int32_t pos, int64_t) { ccount[pos + 1]++; });
         int64_t total = 0;
@@ -483,12 +511,18 @@ void mgbhip_problem::ensure_plan(int level) {
         L.cmax = 1;
         for (size_t q = 0; q + 1 < ecol_ptr.size(); ++q) L.cmax = std::max(L.cmax, ecol_ptr[q + 1] - ecol_ptr[q]);
         std::vector<int32_t> eoff32(eoff.begin(), eoff.end());
+        if (eoff32.empty()) eoff32.push_back(0);
         L.eoff.upload(eoff32, st);
         L.ecol_ptr.upload(ecol_ptr, st);
         L.ecols.upload(ecols.data(), ecols.size(), st);
         L.panels.upload(panels.data(), panels.size(), st);
         if (ecols.empty()) { L.ecols.alloc(1); L.panels.alloc(1); }
         L.slab.alloc((size_t)std::max<int64_t>(L.slab_doubles, 1));
+        if (L.acc) {
+            // one accumulator per wave of a persistent grid: about 32 elements per wave
+            L.acc_waves = (int32_t)std::min<int64_t>(1024, std::max<int64_t>(4, (NE + 31) / 32));
+            L.acc_copies.alloc((size_t)L.acc_waves * (size_t)(m * m));
+        }
         MGB_HIP_CHECK(hipStreamSynchronize(st));
     }
     MGB_HIP_CHECK(hipStreamSynchronize(st));
@@ -614,8 +648,12 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
             PP.p = p; PP.nu = nu; PP.N = N;
             PP.ecol_ptr = L.ecol_ptr.p; PP.panels = L.panels.p; PP.eoff = L.eoff.p;
             PP.hel = d_hel.p; PP.slab = L.slab.p; PP.cmax = L.cmax;
-            launch_panel_project(PP, st);
-            launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st);
+            if (L.acc) {
+                launch_panel_accumulate(PP, L.ecols.p, (int32_t)L.m, L.acc_waves, L.acc_copies.p, L.Hval.p, st);
+            } else {
+                launch_panel_project(PP, st);
+                launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st);
+            }
         }
     }
     L.have_H = true;

@@ -37,6 +37,9 @@ struct Level {
     // assembly plan for H = R' H_blk R (reference: BlockAssemblyPlan, src/BlockMatrices.jl:281-491)
     bool planned = false;
     bool selection = false;               // every row of R has at most one entry, equal to 1
+    bool acc = false;                     // small coarse level: dense H from per-wave accumulators
+    int32_t acc_waves = 0;
+    DevBuf<double> acc_copies;
     std::vector<int32_t> hHptr, hHcol;
     DevBuf<int32_t> Hptr, Hcol, cptr, cidx, ecol_ptr, ecols, eoff;
     DevBuf<double> Hval, panels, slab;
