@@ -661,48 +661,87 @@ __global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P)
 // accumulator (L2/MALL resident), adds the blocks of its elements in element order, and a second
 // kernel sums the accumulators in wave order: deterministic, and the slab round trip disappears.
 __global__ __launch_bounds__(256) void panel_accumulate_kernel(const PanelParams P, const int32_t* __restrict__ ecols,
-                                                               int32_t m, int32_t nwaves, double* __restrict__ copies) {
+                                                               int32_t m, int32_t nwaves, int32_t ctmax,
+                                                               double* __restrict__ copies) {
     extern __shared__ double sh[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * 4 + wave;
     if (gw >= nwaves) return;
     const int p = P.p, nu = P.nu;
-    double* tmp = sh + (size_t)wave * p * P.cmax;
+    const int nblk = nu * (nu + 1) / 2;
+    // per-wave LDS: panels [p][ct], element blocks [nblk][p*p], T = Hel * panels [nu*p][ct], columns, states
+    const size_t per_wave = (size_t)p * ctmax + (size_t)nblk * p * p + (size_t)nu * p * ctmax + ctmax;
+    double* Pl = sh + (size_t)wave * per_wave;          // Pl[rr + p*j]: row rr of the panel column j (own state only)
+    double* Hl = Pl + (size_t)p * ctmax;                // Hl[blk*p*p + rr + p*ss]
+    double* Tl = Hl + (size_t)nblk * p * p;             // Tl[(a*p + rr) + nu*p*j]
+    int32_t* cl = reinterpret_cast<int32_t*>(Tl + (size_t)nu * p * ctmax);   // cl[j] global column, cl[ctmax + j] state
     double* Hp = copies + (int64_t)gw * m * m;
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     for (int64_t e = gw; e < P.N; e += nwaves) {
-        for (int a = 0; a < nu; ++a) {
-            const int32_t oa = P.ecol_ptr[e * nu + a], ca = P.ecol_ptr[e * nu + a + 1] - oa;
-            const double* pa = P.panels + (int64_t)p * oa;
-            for (int b = a; b < nu; ++b) {           // upper block triangle; (b, a) is its mirror
-                const int32_t ob = P.ecol_ptr[e * nu + b], cb = P.ecol_ptr[e * nu + b + 1] - ob;
-                const double* pb = P.panels + (int64_t)p * ob;
-                const int blk = a * nu - (a * (a - 1)) / 2 + (b - a);
-                const double* Hb = P.hel + ((int64_t)blk * P.N + e) * (int64_t)p * p;
-                for (int t = lane; t < p * cb; t += 64) {
-                    const int rr = t % p, ib = t / p;
-                    double acc = 0.0;
-                    for (int ss = 0; ss < p; ++ss) acc += Hb[rr + p * ss] * pb[ss + p * ib];
-                    tmp[t] = acc;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int t = lane; t < ca * cb; t += 64) {
-                    const int ia = t % ca, ib = t / ca;
-                    const int32_t gi = ecols[oa + ia], gj = ecols[ob + ib];
-                    // keep the upper triangle of H (row <= col); within the diagonal block pair
-                    // a == b the (ia, ib) and (ib, ia) entries are equal, one of them is enough
-                    if (a == b && gi > gj) continue;
-                    double acc = 0.0;
-                    for (int rr = 0; rr < p; ++rr) acc += pa[rr + p * ia] * tmp[rr + p * ib];
-                    const int64_t pos = gi <= gj ? (int64_t)gi + (int64_t)m * gj : (int64_t)gj + (int64_t)m * gi;
-                    Hp[pos] += acc;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
+        const int32_t base = P.ecol_ptr[e * nu];
+        const int32_t ct = P.ecol_ptr[(e + 1) * nu] - base;
+        // 1. stage: columns + their state, the panels (contiguous p*ct doubles), the element blocks
+        for (int j = lane; j < ct; j += 64) {
+            cl[j] = ecols[base + j];
+            int st = 0;
+            for (int a = 1; a < nu; ++a)
+                if (base + j >= P.ecol_ptr[e * nu + a]) st = a;
+            cl[ctmax + j] = st;
         }
+        const double* pan = P.panels + (int64_t)p * base;
+        for (int t = lane; t < p * ct; t += 64) Pl[t] = pan[t];
+        for (int t = lane; t < nblk * p * p; t += 64) {
+            const int blk = t / (p * p), q = t - blk * (p * p);
+            Hl[t] = P.hel[((int64_t)blk * P.N + e) * (int64_t)(p * p) + q];
+        }
+        wsync();
+        // 2. T[a][rr][j] = sum_ss Hel_{a, b(j)}[rr][ss] * P[ss][j]
+        for (int t = lane; t < nu * p * ct; t += 64) {
+            const int row = t % (nu * p), j = t / (nu * p);
+            const int a = row / p, rr = row - a * p;
+            const int b = cl[ctmax + j];
+            const bool tr = a > b;
+            const int blk = tr ? (b * nu - (b * (b - 1)) / 2 + (a - b)) : (a * nu - (a * (a - 1)) / 2 + (b - a));
+            const double* Hb = Hl + (size_t)blk * p * p;
+            double acc = 0.0;
+            for (int ss = 0; ss < p; ++ss) acc += (tr ? Hb[ss + p * rr] : Hb[rr + p * ss]) * Pl[ss + p * j];
+            Tl[row + nu * p * j] = acc;
+        }
+        wsync();
+        // 3. B[i][j] = sum_rr P[rr][i] * T[a(i)][rr][j] for column pairs with global index gi <= gj,
+        //    four independent read-modify-writes of the accumulator in flight per lane
+        for (int t0 = lane; t0 < ct * ct; t0 += 4 * 64) {
+            double val[4];
+            int64_t pos[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 64 * u;
+                pos[u] = -1;
+                val[u] = 0.0;
+                if (t < ct * ct) {
+                    const int i = t % ct, j = t / ct;
+                    const int32_t gi = cl[i], gj = cl[j];
+                    if (gi <= gj) {
+                        const int a = cl[ctmax + i];
+                        double acc = 0.0;
+                        for (int rr = 0; rr < p; ++rr) acc += Pl[rr + p * i] * Tl[(a * p + rr) + nu * p * j];
+                        val[u] = acc;
+                        pos[u] = (int64_t)gi + (int64_t)m * gj;
+                    }
+                }
+            }
+            double old[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) old[u] = pos[u] >= 0 ? Hp[pos[u]] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (pos[u] >= 0) Hp[pos[u]] = old[u] + val[u];
+        }
+        wsync();
     }
 }
 
@@ -938,15 +977,20 @@ void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cid
     MGB_HIP_CHECK(hipGetLastError());
 }
 
-void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t m, int32_t nwaves, double* copies,
-                             double* H, hipStream_t st) {
+size_t panel_accumulate_lds(int p, int nu, int ctmax) {
+    const size_t per_wave = (size_t)p * ctmax + (size_t)(nu * (nu + 1) / 2) * p * p + (size_t)nu * p * ctmax + ctmax;
+    return 4 * per_wave * sizeof(double);
+}
+
+void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t m, int32_t nwaves, int32_t ctmax,
+                             double* copies, double* H, hipStream_t st) {
     if (m == 0) return;
     MGB_HIP_CHECK(hipMemsetAsync(copies, 0, sizeof(double) * (size_t)nwaves * m * m, st));
     if (P.N > 0) {
-        const size_t lds = (size_t)4 * P.p * P.cmax * sizeof(double);
+        const size_t lds = panel_accumulate_lds(P.p, P.nu, ctmax);
         MGB_REQUIRE(lds <= 64 * 1024, "coarse-level panels too wide for the accumulation kernel");
         hipLaunchKernelGGL(panel_accumulate_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), lds, st, P, ecols, m,
-                           nwaves, copies);
+                           nwaves, ctmax, copies);
     }
     hipLaunchKernelGGL(accumulate_reduce_kernel, dim3((unsigned)(((int64_t)m * m + 255) / 256)), dim3(256), 0, st, m,
                        nwaves, copies, H);

@@ -337,13 +337,15 @@ void mgbhip_problem::ensure_plan(int level) {
         // worth it only when the per-element slab (sum of ct^2 doubles, written and read back) is
         // at least half the size of the accumulators (zeroed and summed; measured break-even, the
         // long gather lists cost more than their bytes): wide coarse supports, i.e. 3-D
-        int64_t slab_est = 0;
+        int64_t slab_est = 0, ctmax = 1;
         for (int64_t e = 0; e < NE; ++e) {
             const int64_t ct = ecol_ptr[(e + 1) * nu] - ecol_ptr[e * nu];
             slab_est += ct * ct;
+            ctmax = std::max(ctmax, ct);
         }
+        L.acc_ctmax = (int32_t)ctmax;
         const int64_t waves = std::min<int64_t>(1024, std::max<int64_t>(4, (NE + 31) / 32));
-        L.acc = !selection && m > 0 && m <= ACC_MAX_M && (size_t)4 * pp * cmax_all * sizeof(double) <= 64 * 1024 &&
+        L.acc = !selection && m > 0 && m <= ACC_MAX_M && panel_accumulate_lds(pp, nu, (int)ctmax) <= 64 * 1024 &&
                 2 * slab_est > waves * m * m;
         if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
             fprintf(stderr, "[mgbhip] assembly plan level %d: m=%lld selection=%d cmax=%d slab=%lld doubles, accumulators=%lld -> %s\n", level,
@@ -649,7 +651,7 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
             PP.ecol_ptr = L.ecol_ptr.p; PP.panels = L.panels.p; PP.eoff = L.eoff.p;
             PP.hel = d_hel.p; PP.slab = L.slab.p; PP.cmax = L.cmax;
             if (L.acc) {
-                launch_panel_accumulate(PP, L.ecols.p, (int32_t)L.m, L.acc_waves, L.acc_copies.p, L.Hval.p, st);
+                launch_panel_accumulate(PP, L.ecols.p, (int32_t)L.m, L.acc_waves, L.acc_ctmax, L.acc_copies.p, L.Hval.p, st);
             } else {
                 launch_panel_project(PP, st);
                 launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st);
