@@ -988,7 +988,13 @@ void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t
     MGB_HIP_CHECK(hipMemsetAsync(copies, 0, sizeof(double) * (size_t)nwaves * m * m, st));
     if (P.N > 0) {
         const size_t lds = panel_accumulate_lds(P.p, P.nu, ctmax);
-        MGB_REQUIRE(lds <= 64 * 1024, "coarse-level panels too wide for the accumulation kernel");
+        MGB_REQUIRE(lds <= PANEL_ACC_LDS_MAX, "coarse-level panels too wide for the accumulation kernel");
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute((const void*)panel_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)PANEL_ACC_LDS_MAX);
+            (void)hipGetLastError();
+        });
         hipLaunchKernelGGL(panel_accumulate_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), lds, st, P, ecols, m,
                            nwaves, ctmax, copies);
     }

@@ -94,6 +94,7 @@ struct PanelParams {
 void launch_panel_project(const PanelParams& P, hipStream_t st);
 // small coarse levels: per-wave dense accumulators + fixed-order sum instead of slab + gather;
 // H is the dense m x m array (symmetric, both triangles written), copies holds nwaves*m*m doubles
+constexpr size_t PANEL_ACC_LDS_MAX = 144 * 1024;          // one workgroup (4 waves) per CU at the limit
 size_t panel_accumulate_lds(int p, int nu, int ctmax);     // ctmax = largest total column count of an element
 void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t m, int32_t nwaves, int32_t ctmax,
                              double* copies, double* H, hipStream_t st);

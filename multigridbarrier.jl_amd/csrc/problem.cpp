@@ -12,7 +12,8 @@
 
 using namespace mgbhip;
 
-static constexpr int64_t ACC_MAX_M = 384;   // general levels up to this size assemble a dense H from per-wave accumulators
+static constexpr int64_t ACC_MAX_M = 384;
+static constexpr int64_t ACC_MAX_DOUBLES = 8 << 20;   // 64 MB of accumulators   // general levels up to this size assemble a dense H from per-wave accumulators
 
 // ---------------------------------------------------------------------------------------------
 // problem construction
@@ -345,8 +346,9 @@ void mgbhip_problem::ensure_plan(int level) {
         }
         L.acc_ctmax = (int32_t)ctmax;
         const int64_t waves = std::min<int64_t>(1024, std::max<int64_t>(4, (NE + 31) / 32));
-        L.acc = !selection && m > 0 && m <= ACC_MAX_M && panel_accumulate_lds(pp, nu, (int)ctmax) <= 64 * 1024 &&
-                2 * slab_est > waves * m * m;
+        L.acc = !selection && m > 0 && m <= ACC_MAX_M && panel_accumulate_lds(pp, nu, (int)ctmax) <= PANEL_ACC_LDS_MAX &&
+                2 * slab_est > waves * m * m &&
+                waves * m * m <= ACC_MAX_DOUBLES;     // accumulators must stay cache resident (measured: 27 MB wins, 440 MB loses)
         if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
             fprintf(stderr, "[mgbhip] assembly plan level %d: m=%lld selection=%d cmax=%d slab=%lld doubles, accumulators=%lld -> %s\n", level,
                     (long long)m, (int)selection, cmax_all, (long long)slab_est, (long long)(waves * m * m), L.acc ? "dense accumulate" : "slab + gather");
