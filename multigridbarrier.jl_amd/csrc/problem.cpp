@@ -4,6 +4,7 @@
 #include "dense.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -287,6 +288,15 @@ void mgbhip_problem::ensure_plan(int level) {
     Level& L = levels[level];
     if (L.planned) return;
     if (dense) { ensure_plan_dense(level); return; }
+    const auto t_plan0 = std::chrono::steady_clock::now();
+    struct PlanTimer {
+        std::chrono::steady_clock::time_point t0; int level;
+        ~PlanTimer() {
+            if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
+                fprintf(stderr, "[mgbhip] assembly plan level %d built in %.2f s\n", level,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+    } plan_timer{t_plan0, level};
     hipStream_t st = stream();
     const int64_t NE = N;
     const int pp = p;
@@ -477,8 +487,16 @@ void mgbhip_problem::ensure_plan(int level) {
         }
     };
     if (!L.acc) {
+        // one pass over the contributions: remember (position, source) pairs so that the binary
+        // searches behind `find` run once, then bucket them by position
         std::vector<int32_t> ccount(L.nnz + 1, 0);
-        for_each([&](int32_t pos, int64_t) { ccount[pos + 1]++; });
+        std::vector<int32_t> ppos, psrc;
+        for_each([&](int32_t pos, int64_t src) {
+            MGB_REQUIRE(src < (int64_t)INT32_MAX, "slab exceeds 32-bit indexing");
+            ccount[pos + 1]++;
+            ppos.push_back(pos);
+            psrc.push_back((int32_t)src);
+        });
         int64_t total = 0;
         for (int64_t q = 0; q < L.nnz; ++q) {
             total += ccount[q + 1];
@@ -488,10 +506,7 @@ void mgbhip_problem::ensure_plan(int level) {
         L.long_lists = L.nnz > 0 && total / L.nnz > 48;
         std::vector<int32_t> fill(ccount.begin(), ccount.end() - 1);
         std::vector<int32_t> cidx((size_t)total);
-        for_each([&](int32_t pos, int64_t src) {
-            MGB_REQUIRE(src < (int64_t)INT32_MAX, "slab exceeds 32-bit indexing");
-            cidx[fill[pos]++] = (int32_t)src;
-        });
+        for (size_t t = 0; t < ppos.size(); ++t) cidx[fill[ppos[t]]++] = psrc[t];   // element order within a list
         L.cptr.upload(ccount, st);
         L.cidx.upload(cidx.data(), cidx.size(), st);
         if (cidx.empty()) L.cidx.alloc(1);
@@ -669,7 +684,13 @@ void mgbhip_problem::factor(int level) {
     Level& L = levels[level];
     MGB_REQUIRE(L.have_H, "solve requested before any Hessian was assembled at this level");
     hipStream_t st = stream();
-    if (!L.solver.analyzed) L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st);
+    if (!L.solver.analyzed) {
+        const auto t0 = std::chrono::steady_clock::now();
+        L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st);
+        if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
+            fprintf(stderr, "[mgbhip] symbolic analysis level %d (m=%lld, nnz=%lld): %.2f s\n", level, (long long)L.m,
+                    (long long)L.nnz, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
     L.solver.factor(L.Hval.p, st, &ctx->timers);
     L.factored = true;
     cnt.factor++;
