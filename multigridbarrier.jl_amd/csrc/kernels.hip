@@ -745,6 +745,71 @@ __global__ __launch_bounds__(256) void panel_accumulate_kernel(const PanelParams
     }
 }
 
+// Slab variant of the same staging (levels that keep the slab + gather path): the element's
+// panels, blocks and T = Hel * P live in LDS, the ct x ct projected block is written with flat
+// coalesced stores.  Replaces the per-block-pair loops of panel_project_kernel, which re-read the
+// panels from L2 for every output entry.
+__global__ __launch_bounds__(256) void panel_project_staged_kernel(const PanelParams P, int32_t ctmax) {
+    extern __shared__ double sh[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+    if (e >= P.N) return;
+    const int p = P.p, nu = P.nu;
+    const int nblk = nu * (nu + 1) / 2;
+    const size_t per_wave = (size_t)p * ctmax + (size_t)nblk * p * p + (size_t)nu * p * ctmax + ctmax;
+    double* Pl = sh + (size_t)wave * per_wave;
+    double* Hl = Pl + (size_t)p * ctmax;
+    double* Tl = Hl + (size_t)nblk * p * p;
+    int32_t* sl = reinterpret_cast<int32_t*>(Tl + (size_t)nu * p * ctmax);   // sl[j]: state of column j
+    const int32_t base = P.ecol_ptr[e * nu];
+    const int32_t ct = P.ecol_ptr[(e + 1) * nu] - base;
+    for (int j = lane; j < ct; j += 64) {
+        int st = 0;
+        for (int a = 1; a < nu; ++a)
+            if (base + j >= P.ecol_ptr[e * nu + a]) st = a;
+        sl[j] = st;
+    }
+    const double* pan = P.panels + (int64_t)p * base;
+    for (int t = lane; t < p * ct; t += 64) Pl[t] = pan[t];
+    for (int blk = 0; blk < nblk; ++blk) {
+        const double* hb = P.hel + ((int64_t)blk * P.N + e) * (int64_t)(p * p);
+        for (int q = lane; q < p * p; q += 64) Hl[blk * p * p + q] = hb[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nrow = nu * p;
+    const float inv_nrow = 1.0f / (float)nrow, inv_ct = 1.0f / (float)ct;
+    for (int t = lane; t < nrow * ct; t += 64) {
+        int j = (int)(((float)t + 0.5f) * inv_nrow);
+        if (j * nrow > t) --j;
+        if ((j + 1) * nrow <= t) ++j;
+        const int row = t - j * nrow;
+        const int a = row / p, rr = row - a * p;
+        const int b = sl[j];
+        const bool tr = a > b;
+        const int blk = tr ? (b * nu - (b * (b - 1)) / 2 + (a - b)) : (a * nu - (a * (a - 1)) / 2 + (b - a));
+        const double* Hb = Hl + (size_t)blk * p * p;
+        double acc = 0.0;
+        for (int ss = 0; ss < p; ++ss) acc += (tr ? Hb[ss + p * rr] : Hb[rr + p * ss]) * Pl[ss + p * j];
+        Tl[row + nrow * j] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double* out = P.slab + P.eoff[e];
+    for (int t = lane; t < ct * ct; t += 64) {
+        int j = (int)(((float)t + 0.5f) * inv_ct);
+        if (j * ct > t) --j;
+        if ((j + 1) * ct <= t) ++j;
+        const int i = t - j * ct;
+        const int a = sl[i];
+        double acc = 0.0;
+        for (int rr = 0; rr < p; ++rr) acc += Pl[rr + p * i] * Tl[(a * p + rr) + nrow * j];
+        out[t] = acc;                       // out[i + ct * j]
+    }
+}
+
 // H[i, j] = H[j, i] = sum over the accumulators, in wave order (i <= j)
 __global__ __launch_bounds__(256) void accumulate_reduce_kernel(int32_t m, int32_t nwaves, const double* __restrict__ copies,
                                                                 double* __restrict__ H) {
@@ -1000,6 +1065,20 @@ void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t
     }
     hipLaunchKernelGGL(accumulate_reduce_kernel, dim3((unsigned)(((int64_t)m * m + 255) / 256)), dim3(256), 0, st, m,
                        nwaves, copies, H);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_panel_project_staged(const PanelParams& P, int32_t ctmax, hipStream_t st) {
+    if (P.N == 0) return;
+    const size_t lds = panel_accumulate_lds(P.p, P.nu, ctmax);
+    MGB_REQUIRE(lds <= PANEL_ACC_LDS_MAX, "coarse-level panels too wide for the staged projection kernel");
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)panel_project_staged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)PANEL_ACC_LDS_MAX);
+        (void)hipGetLastError();
+    });
+    hipLaunchKernelGGL(panel_project_staged_kernel, dim3((unsigned)((P.N + 3) / 4)), dim3(256), lds, st, P, ctmax);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

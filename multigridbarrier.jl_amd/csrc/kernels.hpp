@@ -92,6 +92,8 @@ struct PanelParams {
     int32_t cmax;                 // largest per-(element, state) column count
 };
 void launch_panel_project(const PanelParams& P, hipStream_t st);
+// same result from LDS-staged panels (needs panel_accumulate_lds(p, nu, ctmax) <= PANEL_ACC_LDS_MAX)
+void launch_panel_project_staged(const PanelParams& P, int32_t ctmax, hipStream_t st);
 // small coarse levels: per-wave dense accumulators + fixed-order sum instead of slab + gather;
 // H is the dense m x m array (symmetric, both triangles written), copies holds nwaves*m*m doubles
 constexpr size_t PANEL_ACC_LDS_MAX = 144 * 1024;          // one workgroup (4 waves) per CU at the limit

@@ -670,7 +670,9 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
             if (L.acc) {
                 launch_panel_accumulate(PP, L.ecols.p, (int32_t)L.m, L.acc_waves, L.acc_ctmax, L.acc_copies.p, L.Hval.p, st);
             } else {
-                launch_panel_project(PP, st);
+                // staged variant while four workgroups still fit a CU (narrow supports: 2-D hierarchies)
+                if (panel_accumulate_lds(p, nu, L.acc_ctmax) <= 40 * 1024) launch_panel_project_staged(PP, L.acc_ctmax, st);
+                else launch_panel_project(PP, st);
                 launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st);
             }
         }
