@@ -655,37 +655,36 @@ __global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P)
     }
 }
 
-// Small coarse levels (m <= ACC_MAX_M unknowns): the projected element blocks overlap almost
-// everywhere (a coarse basis function spans a large part of the mesh), so a per-element slab is
-// m-independent gigabytes.  Instead every wave of a persistent grid owns a private dense m x m
-// accumulator (L2/MALL resident), adds the blocks of its elements in element order, and a second
-// kernel sums the accumulators in wave order: deterministic, and the slab round trip disappears.
+// Small coarse levels whose basis functions overlap almost everywhere (3-D hierarchies): a per-element
+// slab would hold sum_e ct_e^2 doubles for an m x m system of a few hundred unknowns, and the gather
+// behind it reads them back at random.  Instead a workgroup owns a stream of elements and a chunk of the
+// packed upper triangle of H as an LDS accumulator: per element the panels, blocks and T = Hel * P are
+// staged in LDS, the projected entries that fall into the chunk are added in place (no global
+// read-modify-write, no atomics), and at the end the chunk goes to the stream's partial result.  A
+// second kernel sums the streams in order.  Deterministic; traffic = inputs + nstream * m^2 / 2 doubles.
 __global__ __launch_bounds__(256) void panel_accumulate_kernel(const PanelParams P, const int32_t* __restrict__ ecols,
-                                                               int32_t m, int32_t nwaves, int32_t ctmax,
-                                                               double* __restrict__ copies) {
+                                                               int32_t m, int32_t ctmax, int32_t chunk,
+                                                               double* __restrict__ partial) {
     extern __shared__ double sh[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gw = blockIdx.x * 4 + wave;
-    if (gw >= nwaves) return;
+    const int tid = threadIdx.x;
+    const int nstream = gridDim.x, stream = blockIdx.x;
     const int p = P.p, nu = P.nu;
     const int nblk = nu * (nu + 1) / 2;
-    // per-wave LDS: panels [p][ct], element blocks [nblk][p*p], T = Hel * panels [nu*p][ct], columns, states
-    const size_t per_wave = (size_t)p * ctmax + (size_t)nblk * p * p + (size_t)nu * p * ctmax + ctmax;
-    double* Pl = sh + (size_t)wave * per_wave;          // Pl[rr + p*j]: row rr of the panel column j (own state only)
-    double* Hl = Pl + (size_t)p * ctmax;                // Hl[blk*p*p + rr + p*ss]
-    double* Tl = Hl + (size_t)nblk * p * p;             // Tl[(a*p + rr) + nu*p*j]
-    int32_t* cl = reinterpret_cast<int32_t*>(Tl + (size_t)nu * p * ctmax);   // cl[j] global column, cl[ctmax + j] state
-    double* Hp = copies + (int64_t)gw * m * m;
-    auto wsync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    for (int64_t e = gw; e < P.N; e += nwaves) {
+    const int64_t mt = (int64_t)m * (m + 1) / 2;       // packed upper triangle: (gi <= gj) at gi + gj (gj + 1) / 2
+    const int64_t lo = (int64_t)blockIdx.y * chunk;
+    const int64_t hi = lo + chunk < mt ? lo + chunk : mt;
+    double* acc = sh;                                  // [chunk]
+    double* Pl = acc + chunk;                          // Pl[rr + p*j]
+    double* Hl = Pl + (size_t)p * ctmax;               // Hl[blk*p*p + rr + p*ss]
+    double* Tl = Hl + (size_t)nblk * p * p;            // Tl[(a*p + rr) + nu*p*j]
+    int32_t* cl = reinterpret_cast<int32_t*>(Tl + (size_t)nu * p * ctmax);   // cl[j] column, cl[ctmax + j] state
+    for (int t = tid; t < chunk; t += 256) acc[t] = 0.0;
+    const int nrow = nu * p;
+    for (int64_t e = stream; e < P.N; e += nstream) {
         const int32_t base = P.ecol_ptr[e * nu];
         const int32_t ct = P.ecol_ptr[(e + 1) * nu] - base;
-        // 1. stage: columns + their state, the panels (contiguous p*ct doubles), the element blocks
-        for (int j = lane; j < ct; j += 64) {
+        __syncthreads();                               // previous element's LDS operands are no longer read
+        for (int j = tid; j < ct; j += 256) {
             cl[j] = ecols[base + j];
             int st = 0;
             for (int a = 1; a < nu; ++a)
@@ -693,56 +692,69 @@ __global__ __launch_bounds__(256) void panel_accumulate_kernel(const PanelParams
             cl[ctmax + j] = st;
         }
         const double* pan = P.panels + (int64_t)p * base;
-        for (int t = lane; t < p * ct; t += 64) Pl[t] = pan[t];
-        for (int t = lane; t < nblk * p * p; t += 64) {
+        for (int t = tid; t < p * ct; t += 256) Pl[t] = pan[t];
+        for (int t = tid; t < nblk * p * p; t += 256) {
             const int blk = t / (p * p), q = t - blk * (p * p);
             Hl[t] = P.hel[((int64_t)blk * P.N + e) * (int64_t)(p * p) + q];
         }
-        wsync();
-        // 2. T[a][rr][j] = sum_ss Hel_{a, b(j)}[rr][ss] * P[ss][j]
-        for (int t = lane; t < nu * p * ct; t += 64) {
-            const int row = t % (nu * p), j = t / (nu * p);
+        __syncthreads();
+        const float inv_nrow = 1.0f / (float)nrow, inv_ct = 1.0f / (float)ct;
+        for (int t = tid; t < nrow * ct; t += 256) {   // T[a][rr][j] = sum_ss Hel_{a, b(j)}[rr][ss] * P[ss][j]
+            int j = (int)(((float)t + 0.5f) * inv_nrow);
+            if (j * nrow > t) --j;
+            if ((j + 1) * nrow <= t) ++j;
+            const int row = t - j * nrow;
             const int a = row / p, rr = row - a * p;
             const int b = cl[ctmax + j];
             const bool tr = a > b;
             const int blk = tr ? (b * nu - (b * (b - 1)) / 2 + (a - b)) : (a * nu - (a * (a - 1)) / 2 + (b - a));
             const double* Hb = Hl + (size_t)blk * p * p;
-            double acc = 0.0;
-            for (int ss = 0; ss < p; ++ss) acc += (tr ? Hb[ss + p * rr] : Hb[rr + p * ss]) * Pl[ss + p * j];
-            Tl[row + nu * p * j] = acc;
+            double v = 0.0;
+            for (int ss = 0; ss < p; ++ss) v += (tr ? Hb[ss + p * rr] : Hb[rr + p * ss]) * Pl[ss + p * j];
+            Tl[row + nrow * j] = v;
         }
-        wsync();
-        // 3. B[i][j] = sum_rr P[rr][i] * T[a(i)][rr][j] for column pairs with global index gi <= gj,
-        //    four independent read-modify-writes of the accumulator in flight per lane
-        for (int t0 = lane; t0 < ct * ct; t0 += 4 * 64) {
-            double val[4];
-            int64_t pos[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = t0 + 64 * u;
-                pos[u] = -1;
-                val[u] = 0.0;
-                if (t < ct * ct) {
-                    const int i = t % ct, j = t / ct;
-                    const int32_t gi = cl[i], gj = cl[j];
-                    if (gi <= gj) {
-                        const int a = cl[ctmax + i];
-                        double acc = 0.0;
-                        for (int rr = 0; rr < p; ++rr) acc += Pl[rr + p * i] * Tl[(a * p + rr) + nu * p * j];
-                        val[u] = acc;
-                        pos[u] = (int64_t)gi + (int64_t)m * gj;
-                    }
-                }
-            }
-            double old[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) old[u] = pos[u] >= 0 ? Hp[pos[u]] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (pos[u] >= 0) Hp[pos[u]] = old[u] + val[u];
+        __syncthreads();
+        for (int t = tid; t < ct * ct; t += 256) {     // B[i][j] for gi <= gj inside this workgroup's chunk
+            int j = (int)(((float)t + 0.5f) * inv_ct);
+            if (j * ct > t) --j;
+            if ((j + 1) * ct <= t) ++j;
+            const int i = t - j * ct;
+            const int32_t gi = cl[i], gj = cl[j];
+            if (gi > gj) continue;
+            const int64_t pos = (int64_t)gi + ((int64_t)gj * (gj + 1)) / 2;
+            if (pos < lo || pos >= hi) continue;
+            const int a = cl[ctmax + i];
+            double v = 0.0;
+            for (int rr = 0; rr < p; ++rr) v += Pl[rr + p * i] * Tl[(a * p + rr) + nrow * j];
+            acc[pos - lo] += v;                        // distinct (gi, gj) per thread within an element
         }
-        wsync();
     }
+    __syncthreads();
+    double* out = partial + (int64_t)stream * mt + lo;
+    for (int t = tid; t < (int)(hi - lo); t += 256) out[t] = acc[t];
+}
+
+// H[i, j] = H[j, i] = sum over the streams' partial results, in stream order (i <= j)
+__global__ __launch_bounds__(256) void accumulate_reduce_kernel(int32_t m, int32_t nstream, const double* __restrict__ partial,
+                                                                double* __restrict__ H) {
+    const int64_t mt = (int64_t)m * (m + 1) / 2;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (int64_t)m * m) return;
+    const int i = (int)(q % m), j = (int)(q / m);
+    if (i > j) return;
+    const double* src = partial + (int64_t)i + ((int64_t)j * (j + 1)) / 2;
+    double s = 0.0;
+    int w = 0;
+    for (; w + 8 <= nstream; w += 8) {          // eight independent loads in flight, fixed summation order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(w + u) * mt];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; w < nstream; ++w) s += src[(int64_t)w * mt];
+    H[(int64_t)i * m + j] = s;
+    H[(int64_t)j * m + i] = s;
 }
 
 // Slab variant of the same staging (levels that keep the slab + gather path): the element's
@@ -808,19 +820,6 @@ __global__ __launch_bounds__(256) void panel_project_staged_kernel(const PanelPa
         for (int rr = 0; rr < p; ++rr) acc += Pl[rr + p * i] * Tl[(a * p + rr) + nrow * j];
         out[t] = acc;                       // out[i + ct * j]
     }
-}
-
-// H[i, j] = H[j, i] = sum over the accumulators, in wave order (i <= j)
-__global__ __launch_bounds__(256) void accumulate_reduce_kernel(int32_t m, int32_t nwaves, const double* __restrict__ copies,
-                                                                double* __restrict__ H) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q >= (int64_t)m * m) return;
-    const int i = (int)(q % m), j = (int)(q / m);
-    if (i > j) return;
-    double s = 0.0;
-    for (int w = 0; w < nwaves; ++w) s += copies[(int64_t)w * m * m + q];
-    H[(int64_t)i * m + j] = s;
-    H[(int64_t)j * m + i] = s;
 }
 
 template <int NY>
@@ -1042,29 +1041,30 @@ void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cid
     MGB_HIP_CHECK(hipGetLastError());
 }
 
-size_t panel_accumulate_lds(int p, int nu, int ctmax) {
+size_t panel_accumulate_lds(int p, int nu, int ctmax) {      // staging of one element, four waves (slab variant)
     const size_t per_wave = (size_t)p * ctmax + (size_t)(nu * (nu + 1) / 2) * p * p + (size_t)nu * p * ctmax + ctmax;
     return 4 * per_wave * sizeof(double);
 }
 
-void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t m, int32_t nwaves, int32_t ctmax,
-                             double* copies, double* H, hipStream_t st) {
+size_t panel_stage_doubles(int p, int nu, int ctmax) {        // staging of one element, one workgroup
+    return (size_t)p * ctmax + (size_t)(nu * (nu + 1) / 2) * p * p + (size_t)nu * p * ctmax + ctmax;
+}
+
+void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t m, int32_t nstream, int32_t nsplit,
+                             int32_t chunk, int32_t ctmax, double* partial, double* H, hipStream_t st) {
     if (m == 0) return;
-    MGB_HIP_CHECK(hipMemsetAsync(copies, 0, sizeof(double) * (size_t)nwaves * m * m, st));
-    if (P.N > 0) {
-        const size_t lds = panel_accumulate_lds(P.p, P.nu, ctmax);
-        MGB_REQUIRE(lds <= PANEL_ACC_LDS_MAX, "coarse-level panels too wide for the accumulation kernel");
-        static std::once_flag once;
-        std::call_once(once, [] {
-            (void)hipFuncSetAttribute((const void*)panel_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)PANEL_ACC_LDS_MAX);
-            (void)hipGetLastError();
-        });
-        hipLaunchKernelGGL(panel_accumulate_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), lds, st, P, ecols, m,
-                           nwaves, ctmax, copies);
-    }
+    const size_t lds = ((size_t)chunk + panel_stage_doubles(P.p, P.nu, ctmax)) * sizeof(double);
+    MGB_REQUIRE(lds <= PANEL_ACC_LDS_MAX, "coarse-level accumulator + panels exceed the LDS budget");
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)panel_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)PANEL_ACC_LDS_MAX);
+        (void)hipGetLastError();
+    });
+    hipLaunchKernelGGL(panel_accumulate_kernel, dim3((unsigned)nstream, (unsigned)nsplit), dim3(256), lds, st, P, ecols, m,
+                       ctmax, chunk, partial);
     hipLaunchKernelGGL(accumulate_reduce_kernel, dim3((unsigned)(((int64_t)m * m + 255) / 256)), dim3(256), 0, st, m,
-                       nwaves, copies, H);
+                       nstream, partial, H);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

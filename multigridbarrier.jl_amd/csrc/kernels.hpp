@@ -92,13 +92,15 @@ struct PanelParams {
     int32_t cmax;                 // largest per-(element, state) column count
 };
 void launch_panel_project(const PanelParams& P, hipStream_t st);
-// same result from LDS-staged panels (needs panel_accumulate_lds(p, nu, ctmax) <= PANEL_ACC_LDS_MAX)
+// small coarse levels with wide supports: element streams x chunks of the packed upper triangle of H
+// accumulated in LDS, then a fixed-order sum over the streams.  H is the dense m x m array (both
+// triangles written); partial holds nstream * m(m+1)/2 doubles; chunk * nsplit >= m(m+1)/2.
+constexpr size_t PANEL_ACC_LDS_MAX = 144 * 1024;
+size_t panel_accumulate_lds(int p, int nu, int ctmax);     // slab variant: 4 waves x one element's staging
+size_t panel_stage_doubles(int p, int nu, int ctmax);      // one element's staging in doubles
+void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t m, int32_t nstream, int32_t nsplit,
+                             int32_t chunk, int32_t ctmax, double* partial, double* H, hipStream_t st);
+// same projection as launch_panel_project from LDS-staged panels
 void launch_panel_project_staged(const PanelParams& P, int32_t ctmax, hipStream_t st);
-// small coarse levels: per-wave dense accumulators + fixed-order sum instead of slab + gather;
-// H is the dense m x m array (symmetric, both triangles written), copies holds nwaves*m*m doubles
-constexpr size_t PANEL_ACC_LDS_MAX = 144 * 1024;          // one workgroup (4 waves) per CU at the limit
-size_t panel_accumulate_lds(int p, int nu, int ctmax);     // ctmax = largest total column count of an element
-void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t m, int32_t nwaves, int32_t ctmax,
-                             double* copies, double* H, hipStream_t st);
 
 }  // namespace mgbhip

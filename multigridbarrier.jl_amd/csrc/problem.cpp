@@ -14,7 +14,7 @@
 using namespace mgbhip;
 
 static constexpr int64_t ACC_MAX_M = 384;
-static constexpr int64_t ACC_MAX_DOUBLES = 8 << 20;   // 64 MB of accumulators   // general levels up to this size assemble a dense H from per-wave accumulators
+
 
 // ---------------------------------------------------------------------------------------------
 // problem construction
@@ -341,13 +341,10 @@ void mgbhip_problem::ensure_plan(int level) {
     const int64_t m = L.m;
     L.hHptr.assign(m + 1, 0);
     L.hHcol.clear();
-    // Small general levels: dense H through per-wave accumulators (launch_panel_accumulate)
+    // Small general levels with wide supports: dense H through LDS accumulators (launch_panel_accumulate)
     int32_t cmax_all = 1;
     for (size_t q = 0; q + 1 < ecol_ptr.size(); ++q) cmax_all = std::max(cmax_all, ecol_ptr[q + 1] - ecol_ptr[q]);
     {
-        // worth it only when the per-element slab (sum of ct^2 doubles, written and read back) is
-        // at least half the size of the accumulators (zeroed and summed; measured break-even, the
-        // long gather lists cost more than their bytes): wide coarse supports, i.e. 3-D
         int64_t slab_est = 0, ctmax = 1;
         for (int64_t e = 0; e < NE; ++e) {
             const int64_t ct = ecol_ptr[(e + 1) * nu] - ecol_ptr[e * nu];
@@ -355,13 +352,24 @@ void mgbhip_problem::ensure_plan(int level) {
             ctmax = std::max(ctmax, ct);
         }
         L.acc_ctmax = (int32_t)ctmax;
-        const int64_t waves = std::min<int64_t>(1024, std::max<int64_t>(4, (NE + 31) / 32));
-        L.acc = !selection && m > 0 && m <= ACC_MAX_M && panel_accumulate_lds(pp, nu, (int)ctmax) <= PANEL_ACC_LDS_MAX &&
-                2 * slab_est > waves * m * m &&
-                waves * m * m <= ACC_MAX_DOUBLES;     // accumulators must stay cache resident (measured: 27 MB wins, 440 MB loses)
+        // LDS accumulate (launch_panel_accumulate): chunks of the packed upper triangle sized so that
+        // chunk + one element's staging fit the LDS budget; element streams fill the GPU once
+        const int64_t mt = m * (m + 1) / 2;
+        const int64_t stage = (int64_t)panel_stage_doubles(pp, nu, (int)ctmax);
+        const int64_t room = (int64_t)(PANEL_ACC_LDS_MAX / sizeof(double)) - stage;
+        int64_t nsplit = room > 0 ? (mt + room - 1) / room : 1 << 20;
+        if (nsplit < 1) nsplit = 1;
+        const int64_t chunk = (mt + nsplit - 1) / nsplit;
+        const int64_t waves = std::max<int64_t>(8, std::min<int64_t>(NE, (nsplit == 1 ? 512 : 256) / nsplit));
+        L.acc_waves = (int32_t)waves;
+        L.acc_split = (int32_t)nsplit;
+        L.acc_chunk = (int32_t)chunk;
+        // wide coarse supports only (3-D hierarchies): many contributions per entry, few enough
+        // elements per stream; narrow supports are faster through slab + gather
+        L.acc = !selection && m > 0 && m <= ACC_MAX_M && room > 0 && nsplit <= 4 && NE <= 65536 && slab_est >= 16 * mt;
         if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
             fprintf(stderr, "[mgbhip] assembly plan level %d: m=%lld selection=%d cmax=%d slab=%lld doubles, accumulators=%lld -> %s\n", level,
-                    (long long)m, (int)selection, cmax_all, (long long)slab_est, (long long)(waves * m * m), L.acc ? "dense accumulate" : "slab + gather");
+                    (long long)m, (int)selection, cmax_all, (long long)slab_est, (long long)(waves * mt), L.acc ? "LDS accumulate" : "slab + gather");
     }
     if (L.acc) {
         L.hHcol.resize((size_t)(m * m));
@@ -538,9 +546,7 @@ void mgbhip_problem::ensure_plan(int level) {
         if (ecols.empty()) { L.ecols.alloc(1); L.panels.alloc(1); }
         L.slab.alloc((size_t)std::max<int64_t>(L.slab_doubles, 1));
         if (L.acc) {
-            // one accumulator per wave of a persistent grid: about 32 elements per wave
-            L.acc_waves = (int32_t)std::min<int64_t>(1024, std::max<int64_t>(4, (NE + 31) / 32));
-            L.acc_copies.alloc((size_t)L.acc_waves * (size_t)(m * m));
+            L.acc_copies.alloc((size_t)L.acc_waves * (size_t)(m * (m + 1) / 2));
         }
         MGB_HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -668,7 +674,8 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
             PP.ecol_ptr = L.ecol_ptr.p; PP.panels = L.panels.p; PP.eoff = L.eoff.p;
             PP.hel = d_hel.p; PP.slab = L.slab.p; PP.cmax = L.cmax;
             if (L.acc) {
-                launch_panel_accumulate(PP, L.ecols.p, (int32_t)L.m, L.acc_waves, L.acc_ctmax, L.acc_copies.p, L.Hval.p, st);
+                launch_panel_accumulate(PP, L.ecols.p, (int32_t)L.m, L.acc_waves, L.acc_split, L.acc_chunk, L.acc_ctmax,
+                                        L.acc_copies.p, L.Hval.p, st);
             } else {
                 // staged variant while four workgroups still fit a CU (narrow supports: 2-D hierarchies)
                 if (panel_accumulate_lds(p, nu, L.acc_ctmax) <= 40 * 1024) launch_panel_project_staged(PP, L.acc_ctmax, st);

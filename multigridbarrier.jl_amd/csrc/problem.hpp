@@ -38,7 +38,8 @@ struct Level {
     bool planned = false;
     bool selection = false;               // every row of R has at most one entry, equal to 1
     bool acc = false;                     // small coarse level: dense H from per-wave accumulators
-    int32_t acc_waves = 0, acc_ctmax = 0;
+    int32_t acc_waves = 0, acc_ctmax = 0;  // acc_waves: element streams
+    int32_t acc_split = 1, acc_chunk = 0;  // chunks of the packed upper triangle, one per workgroup column
     DevBuf<double> acc_copies;
     std::vector<int32_t> hHptr, hHcol;
     DevBuf<int32_t> Hptr, Hcol, cptr, cidx, ecol_ptr, ecols, eoff;
