@@ -680,24 +680,52 @@ __global__ __launch_bounds__(256) void panel_accumulate_kernel(const PanelParams
     int32_t* cl = reinterpret_cast<int32_t*>(Tl + (size_t)nu * p * ctmax);   // cl[j] column, cl[ctmax + j] state
     for (int t = tid; t < chunk; t += 256) acc[t] = 0.0;
     const int nrow = nu * p;
-    for (int64_t e = stream; e < P.N; e += nstream) {
-        const int32_t base = P.ecol_ptr[e * nu];
-        const int32_t ct = P.ecol_ptr[(e + 1) * nu] - base;
-        __syncthreads();                               // previous element's LDS operands are no longer read
-        for (int j = tid; j < ct; j += 256) {
-            cl[j] = ecols[base + j];
+    // The staging data of the NEXT element travel in registers while the current one is processed
+    // (launch_panel_accumulate guarantees p*ctmax <= 4*256, nblk*p*p <= 3*256, ctmax <= 256).
+    double rP[4], rH[3];
+    int32_t rC = 0, rS = 0, nbase = 0, nct = 0;
+    auto prefetch = [&](int64_t e) {
+        nbase = P.ecol_ptr[e * nu];
+        nct = P.ecol_ptr[(e + 1) * nu] - nbase;
+        if (tid < nct) {
+            rC = ecols[nbase + tid];
             int st = 0;
             for (int a = 1; a < nu; ++a)
-                if (base + j >= P.ecol_ptr[e * nu + a]) st = a;
-            cl[ctmax + j] = st;
+                if (nbase + tid >= P.ecol_ptr[e * nu + a]) st = a;
+            rS = st;
         }
-        const double* pan = P.panels + (int64_t)p * base;
-        for (int t = tid; t < p * ct; t += 256) Pl[t] = pan[t];
-        for (int t = tid; t < nblk * p * p; t += 256) {
-            const int blk = t / (p * p), q = t - blk * (p * p);
-            Hl[t] = P.hel[((int64_t)blk * P.N + e) * (int64_t)(p * p) + q];
+        const double* pan = P.panels + (int64_t)p * nbase;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = tid + 256 * k;
+            rP[k] = t < p * nct ? pan[t] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int t = tid + 256 * k;
+            if (t < nblk * p * p) {
+                const int blk = t / (p * p), q = t - blk * (p * p);
+                rH[k] = P.hel[((int64_t)blk * P.N + e) * (int64_t)(p * p) + q];
+            }
+        }
+    };
+    if (stream < P.N) prefetch(stream);
+    for (int64_t e = stream; e < P.N; e += nstream) {
+        const int32_t ct = nct;
+        __syncthreads();                               // previous element's LDS operands are no longer read
+        if (tid < ct) { cl[tid] = rC; cl[ctmax + tid] = rS; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = tid + 256 * k;
+            if (t < p * ct) Pl[t] = rP[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int t = tid + 256 * k;
+            if (t < nblk * p * p) Hl[t] = rH[k];
         }
         __syncthreads();
+        if (e + nstream < P.N) prefetch(e + nstream);  // in flight during the two product phases below
         const float inv_nrow = 1.0f / (float)nrow, inv_ct = 1.0f / (float)ct;
         for (int t = tid; t < nrow * ct; t += 256) {   // T[a][rr][j] = sum_ss Hel_{a, b(j)}[rr][ss] * P[ss][j]
             int j = (int)(((float)t + 0.5f) * inv_nrow);
@@ -1046,6 +1074,10 @@ size_t panel_accumulate_lds(int p, int nu, int ctmax) {      // staging of one e
     return 4 * per_wave * sizeof(double);
 }
 
+bool panel_accumulate_fits(int p, int nu, int ctmax) {        // register staging limits of panel_accumulate_kernel
+    return p * ctmax <= 4 * 256 && (nu * (nu + 1) / 2) * p * p <= 3 * 256 && ctmax <= 256;
+}
+
 size_t panel_stage_doubles(int p, int nu, int ctmax) {        // staging of one element, one workgroup
     return (size_t)p * ctmax + (size_t)(nu * (nu + 1) / 2) * p * p + (size_t)nu * p * ctmax + ctmax;
 }
@@ -1055,6 +1087,7 @@ void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t
     if (m == 0) return;
     const size_t lds = ((size_t)chunk + panel_stage_doubles(P.p, P.nu, ctmax)) * sizeof(double);
     MGB_REQUIRE(lds <= PANEL_ACC_LDS_MAX, "coarse-level accumulator + panels exceed the LDS budget");
+    MGB_REQUIRE(panel_accumulate_fits(P.p, P.nu, ctmax), "coarse-level panels exceed the register staging of the accumulation kernel");
     static std::once_flag once;
     std::call_once(once, [] {
         (void)hipFuncSetAttribute((const void*)panel_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -98,6 +98,7 @@ void launch_panel_project(const PanelParams& P, hipStream_t st);
 constexpr size_t PANEL_ACC_LDS_MAX = 144 * 1024;
 size_t panel_accumulate_lds(int p, int nu, int ctmax);     // slab variant: 4 waves x one element's staging
 size_t panel_stage_doubles(int p, int nu, int ctmax);      // one element's staging in doubles
+bool panel_accumulate_fits(int p, int nu, int ctmax);       // register-staging limits of the accumulate kernel
 void launch_panel_accumulate(const PanelParams& P, const int32_t* ecols, int32_t m, int32_t nstream, int32_t nsplit,
                              int32_t chunk, int32_t ctmax, double* partial, double* H, hipStream_t st);
 // same projection as launch_panel_project from LDS-staged panels

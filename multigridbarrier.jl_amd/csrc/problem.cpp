@@ -366,7 +366,8 @@ void mgbhip_problem::ensure_plan(int level) {
         L.acc_chunk = (int32_t)chunk;
         // wide coarse supports only (3-D hierarchies): many contributions per entry, few enough
         // elements per stream; narrow supports are faster through slab + gather
-        L.acc = !selection && m > 0 && m <= ACC_MAX_M && room > 0 && nsplit <= 4 && NE <= 65536 && slab_est >= 16 * mt;
+        L.acc = !selection && m > 0 && m <= ACC_MAX_M && room > 0 && nsplit <= 4 && NE <= 65536 && slab_est >= 16 * mt &&
+                panel_accumulate_fits(pp, nu, (int)ctmax);
         if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
             fprintf(stderr, "[mgbhip] assembly plan level %d: m=%lld selection=%d cmax=%d slab=%lld doubles, accumulators=%lld -> %s\n", level,
                     (long long)m, (int)selection, cmax_all, (long long)slab_est, (long long)(waves * mt), L.acc ? "LDS accumulate" : "slab + gather");
