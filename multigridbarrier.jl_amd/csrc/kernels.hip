@@ -742,14 +742,35 @@ __global__ __launch_bounds__(256) void panel_accumulate_kernel(const PanelParams
             Tl[row + nrow * j] = v;
         }
         __syncthreads();
-        for (int t = tid; t < ct * ct; t += 256) {     // B[i][j] for gi <= gj inside this workgroup's chunk
-            int j = (int)(((float)t + 0.5f) * inv_ct);
-            if (j * ct > t) --j;
-            if ((j + 1) * ct <= t) ++j;
-            const int i = t - j * ct;
-            const int32_t gi = cl[i], gj = cl[j];
-            if (gi > gj) continue;
-            const int64_t pos = (int64_t)gi + ((int64_t)gj * (gj + 1)) / 2;
+        // B[i][j] for the pairs i <= j (the element's columns are sorted, so gi <= gj) whose packed
+        // position falls into this workgroup's chunk.  Positions grow with t = i + j (j + 1) / 2, so
+        // the chunk is a contiguous t range: bracket it by columns, then enumerate only that range.
+        int jlo, jhi;
+        {
+            int a0 = 0, a1 = ct;                       // first column whose largest position reaches lo
+            while (a0 < a1) {
+                const int mid = (a0 + a1) >> 1;
+                const int64_t g = cl[mid];
+                if (g + g * (g + 1) / 2 < lo) a0 = mid + 1; else a1 = mid;
+            }
+            jlo = a0;
+            a0 = jlo; a1 = ct;                         // first column whose smallest position is >= hi
+            const int64_t g0 = cl[0];
+            while (a0 < a1) {
+                const int mid = (a0 + a1) >> 1;
+                const int64_t g = cl[mid];
+                if (g0 + g * (g + 1) / 2 < hi) a0 = mid + 1; else a1 = mid;
+            }
+            jhi = a0;
+        }
+        const int tbeg = jlo * (jlo + 1) / 2, tend = jhi * (jhi + 1) / 2;
+        for (int t = tbeg + tid; t < tend; t += 256) {
+            int j = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while ((j + 1) * (j + 2) / 2 <= t) ++j;
+            while (j * (j + 1) / 2 > t) --j;
+            const int i = t - j * (j + 1) / 2;
+            const int64_t gi = cl[i], gj = cl[j];
+            const int64_t pos = gi + gj * (gj + 1) / 2;
             if (pos < lo || pos >= hi) continue;
             const int a = cl[ctmax + i];
             double v = 0.0;
