@@ -726,25 +726,7 @@ __global__ __launch_bounds__(256) void panel_accumulate_kernel(const PanelParams
         }
         __syncthreads();
         if (e + nstream < P.N) prefetch(e + nstream);  // in flight during the two product phases below
-        const float inv_nrow = 1.0f / (float)nrow, inv_ct = 1.0f / (float)ct;
-        for (int t = tid; t < nrow * ct; t += 256) {   // T[a][rr][j] = sum_ss Hel_{a, b(j)}[rr][ss] * P[ss][j]
-            int j = (int)(((float)t + 0.5f) * inv_nrow);
-            if (j * nrow > t) --j;
-            if ((j + 1) * nrow <= t) ++j;
-            const int row = t - j * nrow;
-            const int a = row / p, rr = row - a * p;
-            const int b = cl[ctmax + j];
-            const bool tr = a > b;
-            const int blk = tr ? (b * nu - (b * (b - 1)) / 2 + (a - b)) : (a * nu - (a * (a - 1)) / 2 + (b - a));
-            const double* Hb = Hl + (size_t)blk * p * p;
-            double v = 0.0;
-            for (int ss = 0; ss < p; ++ss) v += (tr ? Hb[ss + p * rr] : Hb[rr + p * ss]) * Pl[ss + p * j];
-            Tl[row + nrow * j] = v;
-        }
-        __syncthreads();
-        // B[i][j] for the pairs i <= j (the element's columns are sorted, so gi <= gj) whose packed
-        // position falls into this workgroup's chunk.  Positions grow with t = i + j (j + 1) / 2, so
-        // the chunk is a contiguous t range: bracket it by columns, then enumerate only that range.
+        // columns whose packed positions can fall into this workgroup's chunk [lo, hi)
         int jlo, jhi;
         {
             int a0 = 0, a1 = ct;                       // first column whose largest position reaches lo
@@ -763,6 +745,25 @@ __global__ __launch_bounds__(256) void panel_accumulate_kernel(const PanelParams
             }
             jhi = a0;
         }
+        const float inv_nrow = 1.0f / (float)nrow;
+        for (int t = tid + nrow * jlo; t < nrow * jhi; t += 256) {   // T[a][rr][j] = sum_ss Hel_{a, b(j)}[rr][ss] * P[ss][j], j in [jlo, jhi)
+            int j = (int)(((float)t + 0.5f) * inv_nrow);
+            if (j * nrow > t) --j;
+            if ((j + 1) * nrow <= t) ++j;
+            const int row = t - j * nrow;
+            const int a = row / p, rr = row - a * p;
+            const int b = cl[ctmax + j];
+            const bool tr = a > b;
+            const int blk = tr ? (b * nu - (b * (b - 1)) / 2 + (a - b)) : (a * nu - (a * (a - 1)) / 2 + (b - a));
+            const double* Hb = Hl + (size_t)blk * p * p;
+            double v = 0.0;
+            for (int ss = 0; ss < p; ++ss) v += (tr ? Hb[ss + p * rr] : Hb[rr + p * ss]) * Pl[ss + p * j];
+            Tl[row + nrow * j] = v;
+        }
+        __syncthreads();
+        // B[i][j] for the pairs i <= j (the element's columns are sorted, so gi <= gj) whose packed
+        // position falls into this workgroup's chunk.  Positions grow with t = i + j (j + 1) / 2, so
+        // the chunk is a contiguous t range: bracket it by columns, then enumerate only that range.
         const int tbeg = jlo * (jlo + 1) / 2, tend = jhi * (jhi + 1) / 2;
         for (int t = tbeg + tid; t < tend; t += 256) {
             int j = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
