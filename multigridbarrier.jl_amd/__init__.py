@@ -13,7 +13,7 @@ from .multigrid import Geometry, MultiGrid, AMG, prepare_amg, amg_helper
 from .fem2d_p2 import fem2d_P2, FEM2D_P2
 from .tensorfem import fem1d, fem2d, fem3d, TensorFEM, tensor_dofmap
 from .spectral import spectral1d, spectral2d, SPECTRAL1D, SPECTRAL2D
-from .amg_prolongators import amg_ruge_stuben
+from .amg_prolongators import amg_ruge_stuben, amg_smoothed_aggregation
 from .convex import Convex, Piece, convex_Euclidian_power, convex_linear, convex_piecewise, intersect
 from .parabolic import parabolic_solve, ParabolicSOL
 from .problem import (MGBProblem, assemble, amg, subdivide, find_boundary, default_f, default_g,

@@ -141,6 +141,107 @@ def amg_ruge_stuben(**kwargs) -> Callable[[sp.spmatrix], List[sp.csr_matrix]]:
     return lambda K: ruge_stuben_prolongations(K, **kwargs)
 
 
+# ---------------------------------------------------------------------------
+# smoothed aggregation (reference: src/amg_prolongators.jl:27-29 ->
+# AlgebraicMultigrid.smoothed_aggregation; published algorithm: Vanek, Mandel, Brezina 1996,
+# the defaults of AlgebraicMultigrid.jl / PyAMG: symmetric strength theta = 0, standard
+# aggregation, constant near-nullspace candidate, Jacobi prolongation smoothing omega = 4/3)
+# ---------------------------------------------------------------------------
+
+def _symmetric_strength(A: sp.csr_matrix, theta: float) -> sp.csr_matrix:
+    """C[i, j] != 0 iff |a_ij| >= theta * sqrt(|a_ii| |a_jj|), i != j."""
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    d = np.abs(A.diagonal())
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    off = rows != A.indices
+    keep = off & (np.abs(A.data) >= theta * np.sqrt(d[rows] * d[A.indices])) & (A.data != 0)
+    return sp.csr_matrix((np.abs(A.data[keep]), (rows[keep], A.indices[keep])), shape=(n, n))
+
+
+def _standard_aggregation(C: sp.csr_matrix) -> np.ndarray:
+    """Three-pass standard aggregation.  Returns the aggregate id per node (-1 = isolated)."""
+    n = C.shape[0]
+    Cp, Cj, Cx = C.indptr, C.indices, C.data
+    agg = np.full(n, -1, dtype=np.int64)
+    na = 0
+    # pass 1: a node whose strong neighbourhood is entirely free seeds an aggregate
+    for i in range(n):
+        if agg[i] >= 0 or Cp[i] == Cp[i + 1]:
+            continue
+        nb = Cj[Cp[i]:Cp[i + 1]]
+        if np.all(agg[nb] < 0):
+            agg[i] = na
+            agg[nb] = na
+            na += 1
+    # pass 2: remaining nodes join the aggregate of their strongest aggregated neighbour
+    agg1 = agg.copy()
+    for i in range(n):
+        if agg[i] >= 0 or Cp[i] == Cp[i + 1]:
+            continue
+        nb = Cj[Cp[i]:Cp[i + 1]]
+        w = Cx[Cp[i]:Cp[i + 1]]
+        ok = agg1[nb] >= 0
+        if ok.any():
+            agg[i] = agg1[nb[ok][np.argmax(w[ok])]]
+    # pass 3: whatever is left forms aggregates with its free neighbours
+    for i in range(n):
+        if agg[i] >= 0 or Cp[i] == Cp[i + 1]:
+            continue
+        nb = Cj[Cp[i]:Cp[i + 1]]
+        free = nb[agg[nb] < 0]
+        agg[i] = na
+        agg[free] = na
+        na += 1
+    return agg
+
+
+def _spectral_radius_DinvA(A: sp.csr_matrix, iters: int = 15) -> float:
+    """Power iteration on D^{-1} A (symmetrically scaled), deterministic start vector."""
+    d = A.diagonal()
+    dis = 1.0 / np.sqrt(np.where(d != 0, np.abs(d), 1.0))
+    x = np.cos(np.arange(A.shape[0]) * 0.7 + 0.3)
+    x /= np.linalg.norm(x)
+    lam = 1.0
+    for _ in range(iters):
+        y = dis * (A @ (dis * x))
+        lam = float(np.linalg.norm(y))
+        if lam == 0:
+            return 1.0
+        x = y / lam
+    return lam
+
+
+def smoothed_aggregation_prolongations(K: sp.spmatrix, max_coarse: int = 10, max_levels: int = 10,
+                                       theta: float = 0.0, omega: float = 4.0 / 3.0) -> List[sp.csr_matrix]:
+    """Level prolongations, finest first."""
+    A = sp.csr_matrix(K).astype(np.float64)
+    Ps: List[sp.csr_matrix] = []
+    while len(Ps) + 1 < max_levels and A.shape[0] > max_coarse:
+        n = A.shape[0]
+        C = _symmetric_strength(A, theta)
+        agg = _standard_aggregation(C)
+        na = int(agg.max()) + 1 if n else 0
+        if na == 0 or na >= n:
+            break
+        keep = agg >= 0
+        counts = np.bincount(agg[keep], minlength=na).astype(np.float64)
+        T = sp.csr_matrix((1.0 / np.sqrt(counts[agg[keep]]), (np.nonzero(keep)[0], agg[keep])), shape=(n, na))
+        d = A.diagonal()
+        dinv = np.where(d != 0, 1.0 / d, 0.0)
+        rho = _spectral_radius_DinvA(A)
+        P = sp.csr_matrix(T - (omega / rho) * (sp.diags(dinv) @ (A @ T)))
+        P.eliminate_zeros()
+        Ps.append(P)
+        A = sp.csr_matrix(P.T @ A @ P)
+    return Ps
+
+
+def amg_smoothed_aggregation(**kwargs) -> Callable[[sp.spmatrix], List[sp.csr_matrix]]:
+    """Factory with the reference's calling convention (reference: src/amg_prolongators.jl:27-29)."""
+    return lambda K: smoothed_aggregation_prolongations(K, **kwargs)
+
+
 def amg_prolongations(K_int: sp.spmatrix, prolongator) -> List[sp.csr_matrix]:
     """reference: src/amg_prolongators.jl:70-78."""
     if K_int.shape[0] == 0:

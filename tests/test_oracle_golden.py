@@ -30,6 +30,16 @@ def test_oracle_reproduces_reference_parabolic_golden(name):
     assert np.linalg.norm(u - np.array(c["u"])) < c["tol"]
 
 
+@pytest.mark.parametrize("name,geom", [("fem1d_5nodes_p1", lambda: m.fem1d(nodes=np.linspace(-1, 1, 5))),
+                                       ("fem2d_P2_L2_p1.5", lambda: m.subdivide(m.fem2d_P2(), 2)),
+                                       ("fem3d_k1_L2_p1", lambda: m.subdivide(m.fem3d(k=1), 2))])
+def test_goldens_are_prolongator_independent(golden, name, geom):
+    # test/test_algebraic.jl:24-31: every prolongator factory must reproduce the same golden z
+    c = golden[name]
+    prob = m.assemble(m.amg(geom(), prolongator=m.amg_smoothed_aggregation(max_coarse=2)), p=c["p"])
+    assert np.linalg.norm(O.mgb_solve(prob)["z"] - gold_z(c)) < c["tol"]
+
+
 def test_linear_cobarrier_hessian_known_answer():
     # test/test_algebraic_coverage.jl:48-59: rectangular linear cobarrier Hessian == B' diag(1/F^2) B
     mg = m.amg(m.fem1d(nodes=np.linspace(-1, 1, 3)))

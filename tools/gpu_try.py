@@ -6,8 +6,9 @@ from mgb_amd.device import DeviceMGBProblem
 from mgb_amd.solve import mgb_driver
 from mgb_amd.amg_prolongators import amg_ruge_stuben
 L = int(sys.argv[1]); p = float(sys.argv[2]); kw = json.loads(sys.argv[3]) if len(sys.argv) > 3 else {}
+factory = m.amg_smoothed_aggregation if os.environ.get('SA') else amg_ruge_stuben
 t0 = time.time()
-prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), L), prolongator=amg_ruge_stuben(**kw)), p=p)
+prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), L), prolongator=factory(**kw)), p=p)
 print('L', L, 'p', p, kw, 'setup %.1f' % (time.time() - t0), 'levels', [R.shape[1] for R in prob.M[0].R_fine], flush=True)
 D = DeviceMGBProblem(prob)
 t0 = time.time()
