@@ -298,6 +298,37 @@ def _full_size_properties(prob, scale, check_solve=True):
         D.close()
 
 
+def test_accumulate_assembly_with_split_chunks_matches_oracle():
+    """fem3d L=6 phase-I image, coarsest level (232 unknowns, every element touches ~37 of them):
+    the LDS-accumulate assembly runs with the packed triangle split over two workgroup columns."""
+    prob = m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 6), prolongator=m.amg_ruge_stuben(max_coarse=300)), p=4.0)
+    D = _device(prob)
+    try:
+        feas = D.feasibility
+        feas.set_box(30.0, 40.0)
+        n = prob.M[0].w.size
+        nD = len(prob.M[0].D_fine)
+        M2 = O.OracleAMG(prob.M[1])
+        Qf = O.FeasConvex(prob.Q, 30.0, 40.0, nD + 1)
+        z1 = np.concatenate([stacked(prob.g), np.full(n, 15.0)])
+        c1 = np.zeros((n, nD + 1 + 2)); c1[:, nD] = 1.0
+        R = M2.R_fine[0]
+        assert R.shape[1] >= 200
+        s = 1e-5 * np.random.default_rng(4).standard_normal(R.shape[1])
+        B = O.Barrier(Qf)
+        H_o = np.asarray(sp.csr_matrix(B.f2(s, M2.w, c1, R, M2.D_fine, z1)).todense())
+        assert np.all(np.isfinite(H_o))
+        H_d = feas.f2(0, s, c1, z1)
+        H_d = np.asarray(H_d.todense()) if sp.issparse(H_d) else np.asarray(H_d)
+        assert abs(H_d - H_o).max() <= KERNEL_RTOL * abs(H_o).max()
+        assert np.array_equal(H_d, H_d.T)
+        H_2 = feas.f2(0, s, c1, z1)
+        H_2 = np.asarray(H_2.todense()) if sp.issparse(H_2) else np.asarray(H_2)
+        assert np.array_equal(H_d, H_2)                                     # fixed summation order
+    finally:
+        D.close()
+
+
 def test_config3_full_size_properties():
     """fem2d_P2 p=1.0 L=9 (BASELINE configs[2], the headline size: 917 504 nodes, 1.31 M unknowns)."""
     prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 9), prolongator=m.amg_ruge_stuben(max_coarse=300)), p=1.0)
