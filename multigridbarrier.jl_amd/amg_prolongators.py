@@ -4,14 +4,22 @@ The reference delegates this step to the third-party AlgebraicMultigrid.jl
 (`ruge_stuben(K; max_coarse=2).levels[i].P`, reference: src/amg_prolongators.jl:16-18),
 which is not vendored and whose exact P entries are therefore *unpinned* (SURVEY.md
 section 8c: the reference's own tests only pin the downstream `z`, which three different
-prolongators reproduce).  This module restates the published classical
-Ruge-Stueben algorithm (Ruge & Stueben 1987; the PyAMG/AlgebraicMultigrid.jl
-variant: absolute-value classical strength with theta = 0.25, first-pass RS C/F
-splitting, direct interpolation).  Setup-only; never on the per-iteration path.
+prolongators reproduce).  This module restates that package's published algorithm
+(Ruge & Stueben 1987 as implemented by AlgebraicMultigrid.jl 1.x, a port of PyAMG's
+`ruge_stuben_solver`):
+
+  * `Classical(0.25)` strength: j strongly influences i iff
+    |a_ij| >= 0.25 * max_{k != i} |a_ik|  (absolute values, explicit zeros dropped);
+  * `RS()` splitting: first pass only, bucket-sorted by lambda with the package's
+    tie-breaking (see `_rs_cf_splitting`), lambda = 0 nodes are F points;
+  * direct interpolation with separate negative/positive coefficient sums;
+  * `while length(levels) + 1 < max_levels && size(A, 1) > max_coarse` with
+    `max_levels = 10`, Galerkin `A <- P' A P`.
+
+Setup-only; never on the per-iteration path.
 """
 from __future__ import annotations
 
-import heapq
 from typing import Callable, List
 
 import numpy as np
@@ -33,45 +41,100 @@ def _classical_strength(A: sp.csr_matrix, theta: float) -> sp.csr_matrix:
     return S
 
 
-def _rs_cf_splitting(S: sp.csr_matrix) -> np.ndarray:
-    """First-pass Ruge-Stueben C/F splitting.  Returns a bool array, True = C point."""
+U_NODE, C_NODE, F_NODE = 2, 1, 0
+
+
+def _rs_cf_splitting(S: sp.csr_matrix, diag_quirk: bool = False) -> np.ndarray:
+    """Ruge-Stueben first-pass C/F splitting with the bucket ("interval") ordering of
+    AlgebraicMultigrid.jl's `RS_CF_splitting` (src/splitting.jl; itself the algorithm of
+    PyAMG's `rs_cf_splitting`).  `S[i, j] != 0` iff i strongly depends on j (no diagonal).
+
+    Nodes are kept sorted by lambda (number of points that strongly depend on the node):
+    `index_to_node[interval_ptr[l] : interval_ptr[l] + interval_count[l]]` holds the nodes of
+    measure l; the initial order inside an interval is by node index.  The node at the top
+    (largest lambda, last in its interval) is taken as a C point; everything that depends on
+    it becomes F, every still-undecided influence of a new F point moves to the END of the next
+    interval (lambda + 1), every undecided influence of the new C point to the BEGINNING of the
+    previous interval (lambda - 1).  Nodes nobody depends on are F from the start and never
+    become C.  There is no second pass.  Returns a bool array, True = C point.
+
+    `diag_quirk`: PyAMG's pre-filter also marks F the nodes with `lambda == 1` whose first
+    stored strength entry is the diagonal; whether the Julia port (whose strength matrix keeps
+    the diagonal, but whose lambda excludes it) applies the same test is not recoverable from
+    the reference tree, so it is an option, off by default (on the BASELINE meshes it moves at most two
+    unknowns between the two coarsest levels)."""
     n = S.shape[0]
     S = sp.csr_matrix(S)
+    S.sort_indices()
     ST = sp.csr_matrix(S.T)
-    Sp, Sj = S.indptr, S.indices
-    Tp, Tj = ST.indptr, ST.indices
-    lam = np.diff(Tp).astype(np.int64)        # number of points each node strongly influences
-    U, C, F = 0, 1, 2
-    state = np.zeros(n, dtype=np.int8)
-    # isolated / uninfluential points: nodes with no strong connections at all become F
-    # only if they influence nobody and depend on nobody -> make them C so P keeps them.
-    heap = [(-int(lam[i]), i) for i in range(n)]
-    heapq.heapify(heap)
-    lam_l = lam.tolist()
-    while heap:
-        negl, i = heapq.heappop(heap)
-        if state[i] != U or -negl != lam_l[i]:
+    ST.sort_indices()
+    Sp, Sj = S.indptr.tolist(), S.indices.tolist()        # S row i: the nodes i depends on
+    Tp, Tj = ST.indptr.tolist(), ST.indices.tolist()      # T row i: the nodes that depend on i
+    lam = [Tp[i + 1] - Tp[i] for i in range(n)]
+    interval_count = [0] * (n + 2)
+    for i in range(n):
+        interval_count[lam[i]] += 1
+    interval_ptr = [0] * (n + 2)
+    cs = 0
+    for l in range(n + 1):
+        interval_ptr[l] = cs
+        cs += interval_count[l]
+        interval_count[l] = 0
+    index_to_node = [0] * n
+    node_to_index = [0] * n
+    for i in range(n):
+        l = lam[i]
+        idx = interval_ptr[l] + interval_count[l]
+        index_to_node[idx] = i
+        node_to_index[i] = idx
+        interval_count[l] += 1
+    split = [U_NODE] * n
+    for i in range(n):
+        if lam[i] == 0:
+            split[i] = F_NODE
+        elif diag_quirk and lam[i] == 1 and (Sp[i] == Sp[i + 1] or Sj[Sp[i]] > i):
+            split[i] = F_NODE
+    for top in range(n - 1, -1, -1):
+        i = index_to_node[top]
+        interval_count[lam[i]] -= 1
+        if split[i] == F_NODE:
             continue
-        state[i] = C
-        # everything that strongly depends on i becomes F
-        for jj in range(Tp[i], Tp[i + 1]):
+        split[i] = C_NODE
+        for jj in range(Tp[i], Tp[i + 1]):              # nodes that depend on the new C point
             j = Tj[jj]
-            if state[j] != U:
+            if split[j] != U_NODE:
                 continue
-            state[j] = F
-            # points that influence the new F point become more attractive as C points
-            for kk in range(Sp[j], Sp[j + 1]):
+            split[j] = F_NODE
+            for kk in range(Sp[j], Sp[j + 1]):          # what the new F point depends on
                 k = Sj[kk]
-                if state[k] == U:
-                    lam_l[k] += 1
-                    heapq.heappush(heap, (-lam_l[k], k))
-        # points that i depends on lose one potential dependent
-        for jj in range(Sp[i], Sp[i + 1]):
+                if split[k] != U_NODE or lam[k] >= n - 1:
+                    continue
+                lk = lam[k]
+                old = node_to_index[k]
+                new = interval_ptr[lk] + interval_count[lk] - 1      # end of its interval
+                a, b = index_to_node[old], index_to_node[new]
+                node_to_index[a], node_to_index[b] = new, old
+                index_to_node[old], index_to_node[new] = b, a
+                interval_count[lk] -= 1
+                interval_count[lk + 1] += 1
+                interval_ptr[lk + 1] = new
+                lam[k] = lk + 1
+        for jj in range(Sp[i], Sp[i + 1]):              # what the new C point depends on
             j = Sj[jj]
-            if state[j] == U:
-                lam_l[j] -= 1
-                heapq.heappush(heap, (-lam_l[j], j))
-    return state == C
+            if split[j] != U_NODE or lam[j] == 0:
+                continue
+            lj = lam[j]
+            old = node_to_index[j]
+            new = interval_ptr[lj]                       # beginning of its interval
+            a, b = index_to_node[old], index_to_node[new]
+            node_to_index[a], node_to_index[b] = new, old
+            index_to_node[old], index_to_node[new] = b, a
+            interval_count[lj] -= 1
+            interval_count[lj - 1] += 1
+            interval_ptr[lj] += 1
+            interval_ptr[lj - 1] = interval_ptr[lj] - interval_count[lj - 1]
+            lam[j] = lj - 1
+    return np.array(split) == C_NODE
 
 
 def _direct_interpolation(A: sp.csr_matrix, S: sp.csr_matrix, is_c: np.ndarray) -> sp.csr_matrix:
@@ -120,13 +183,13 @@ def _direct_interpolation(A: sp.csr_matrix, S: sp.csr_matrix, is_c: np.ndarray) 
 
 
 def ruge_stuben_prolongations(K: sp.spmatrix, max_coarse: int = 2, max_levels: int = 10,
-                              theta: float = 0.25) -> List[sp.csr_matrix]:
+                              theta: float = 0.25, diag_quirk: bool = False) -> List[sp.csr_matrix]:
     """Level prolongations, finest first (the `[lvl.P for lvl in ...levels]` of the reference)."""
     A = sp.csr_matrix(K).astype(np.float64)
     Ps: List[sp.csr_matrix] = []
     while len(Ps) + 1 < max_levels and A.shape[0] > max_coarse:
         S = _classical_strength(A, theta)
-        is_c = _rs_cf_splitting(S)
+        is_c = _rs_cf_splitting(S, diag_quirk)
         nc = int(is_c.sum())
         if nc == 0 or nc == A.shape[0]:
             break

@@ -16,7 +16,26 @@ int matched_t_run(mgbhip_problem* P, const double* z, const double* c, double t_
 
 static thread_local std::string g_last_error;
 
+// Every entry point that takes a handle runs with the handle's device current on the calling
+// thread (and restores the caller's device afterwards): a second context on another GPU, a call
+// from another host thread or a torch.cuda.set_device between calls must not put buffers or
+// launches on the wrong device for ctx->stream.
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) MGB_HIP_CHECK(hipSetDevice(dev));
+    }
+    ~DeviceGuard() {
+        if (dev >= 0 && prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+static int dev_of(const mgbhip_ctx* c) { return c ? c->device : -1; }
+static int dev_of(const mgbhip_problem* p) { return (p && p->ctx) ? p->ctx->device : -1; }
+
 #define MGB_API_BEGIN try {
+#define MGB_API_BEGIN_ON(h) try { DeviceGuard _guard(dev_of(h));
 #define MGB_API_END                                   \
     }                                                 \
     catch (const InvalidArgument& e) {                \
@@ -60,7 +79,7 @@ int mgbhip_create(mgbhip_ctx** out, int device_id, void* hip_stream) {
 }
 
 int mgbhip_destroy(mgbhip_ctx* ctx) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(ctx)
     if (!ctx) return MGBHIP_OK;
     (void)hipStreamSynchronize(ctx->stream);
     ctx->timers.reset(false);
@@ -72,7 +91,7 @@ int mgbhip_destroy(mgbhip_ctx* ctx) {
 
 int mgbhip_problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* desc, mgbhip_problem* share,
                           mgbhip_problem** out) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(ctx)
     MGB_REQUIRE(out != nullptr, "null output pointer");
     *out = problem_create(ctx, desc, share);
     return MGBHIP_OK;
@@ -80,7 +99,7 @@ int mgbhip_problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* desc, mgbh
 }
 
 int mgbhip_problem_destroy(mgbhip_problem* prob) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(prob)
     if (!prob) return MGBHIP_OK;
     (void)hipStreamSynchronize(prob->stream());
     delete prob;
@@ -98,7 +117,7 @@ int mgbhip_problem_set_box(mgbhip_problem* prob, double b, double R) {
 }
 
 int mgbhip_problem_set_barrier_weights(mgbhip_problem* prob, const double* bw) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(prob)
     MGB_REQUIRE(prob, "null problem");
     if (bw) {
         prob->bw.upload(bw, (size_t)prob->n, prob->stream());
@@ -130,7 +149,7 @@ static void stage_inputs(mgbhip_problem* P, int32_t level, const double* s, cons
 }
 
 int mgbhip_f0(mgbhip_problem* P, int32_t level, const double* s, const double* c, const double* z0, double* value) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     check_level(P, level);
     MGB_REQUIRE(s && c && z0 && value, "null argument");
     stage_inputs(P, level, s, c, z0);
@@ -140,7 +159,7 @@ int mgbhip_f0(mgbhip_problem* P, int32_t level, const double* s, const double* c
 }
 
 int mgbhip_f1(mgbhip_problem* P, int32_t level, const double* s, const double* c, const double* z0, double* grad) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     check_level(P, level);
     MGB_REQUIRE(s && c && z0 && grad, "null argument");
     stage_inputs(P, level, s, c, z0);
@@ -152,7 +171,7 @@ int mgbhip_f1(mgbhip_problem* P, int32_t level, const double* s, const double* c
 }
 
 int mgbhip_f2(mgbhip_problem* P, int32_t level, const double* s, const double* c, const double* z0, double* values) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     check_level(P, level);
     MGB_REQUIRE(s && c && z0, "null argument");
     stage_inputs(P, level, s, c, z0);
@@ -165,7 +184,7 @@ int mgbhip_f2(mgbhip_problem* P, int32_t level, const double* s, const double* c
 
 int mgbhip_hessian_pattern(mgbhip_problem* P, int32_t level, int64_t* nnz, const int32_t** rowptr,
                            const int32_t** colidx) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     check_level(P, level);
     P->ensure_plan(level);
     if (nnz) *nnz = P->levels[level].nnz;
@@ -176,7 +195,7 @@ int mgbhip_hessian_pattern(mgbhip_problem* P, int32_t level, int64_t* nnz, const
 }
 
 int mgbhip_solve(mgbhip_problem* P, int32_t level, const double* g, double* x) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     check_level(P, level);
     MGB_REQUIRE(g && x, "null argument");
     hipStream_t st = P->stream();
@@ -209,13 +228,13 @@ static int node_map(mgbhip_problem* P, const double* z, double* F, double* Dz, i
 }
 
 int mgbhip_node_barrier(mgbhip_problem* P, const double* z, double* F, double* Dz) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     return node_map(P, z, F, Dz, MODE_NODE_F);
     MGB_API_END
 }
 
 int mgbhip_node_slack(mgbhip_problem* P, const double* z, double* slack) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     return node_map(P, z, slack, nullptr, MODE_NODE_SLACK);
     MGB_API_END
 }
@@ -238,7 +257,7 @@ void mgbhip_default_options(mgbhip_options* o, int64_t n_nodes) {
 }
 
 int mgbhip_mgb_core(mgbhip_problem* P, double* z, const double* c, const mgbhip_options* opt, mgbhip_core_result* res) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     MGB_REQUIRE(P && z && c && opt && res, "null argument");
     MGB_REQUIRE(opt->tol > 0 && opt->t > 0 && opt->kappa > 1 && opt->maxit >= 1 && opt->max_newton >= 1, "bad options");
     int rc = core_run(P, z, c, opt, res);
@@ -250,14 +269,14 @@ int mgbhip_mgb_core(mgbhip_problem* P, double* z, const double* c, const mgbhip_
 }
 
 int mgbhip_matched_t(mgbhip_problem* P, const double* z, const double* c, double t_default, double* t_out) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     MGB_REQUIRE(P && z && c && t_out, "null argument");
     return matched_t_run(P, z, c, t_default, t_out);
     MGB_API_END
 }
 
 int mgbhip_stage_ms(mgbhip_problem* P, const char* stage, double* total_ms, int64_t* launches) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     MGB_REQUIRE(P && stage, "null argument");
     P->ctx->timers.collect();
     auto it = P->ctx->timers.recs.find(stage);
@@ -286,7 +305,7 @@ int mgbhip_solver_stats(mgbhip_problem* P, int32_t level, double* out) {
 }
 
 int mgbhip_reset_stage_timers(mgbhip_problem* P, int enable) {
-    MGB_API_BEGIN
+    MGB_API_BEGIN_ON(P)
     MGB_REQUIRE(P, "null argument");
     P->ctx->timers.reset(enable != 0);
     return MGBHIP_OK;

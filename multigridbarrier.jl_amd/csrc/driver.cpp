@@ -288,7 +288,8 @@ StepResult mgb_step(mgbhip_problem* P, const double* d_c, const mgbhip_options& 
 }
 
 double c_dot_Dz(mgbhip_problem* P, const double* d_c) {
-    // sum_j dot(w .* c[:, j], (D_j z))  (src/mgb.jl:135-136): the linear part of f0 at s = 0
+    // sum_j dot(w .* c[:, j], (D_j z))  (src/mgb.jl:135-136, :165-166) with the UNSCALED cost grid
+    // c (not t*c): the linear part of f0 at s = 0; invn = 0 switches the barrier term off
     hipStream_t st = P->stream();
     ElemParams E = P->base_params(-1, nullptr, P->d_z.p, d_c);
     E.invn = 0.0;
@@ -365,7 +366,7 @@ int core_run(mgbhip_problem* P, double* z, const double* c, const mgbhip_options
         if (kk - 1 < res->cap_steps) {
             if (res->ts) res->ts[kk - 1] = t;
             if (res->kappas) res->kappas[kk - 1] = kappa;
-            if (res->c_dot_Dz) res->c_dot_Dz[kk - 1] = c_dot_Dz(P, P->d_c.p);
+            if (res->c_dot_Dz) res->c_dot_Dz[kk - 1] = c_dot_Dz(P, P->d_c0.p);
         }
     };
     diag(1);

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void elem_kernel(const ElemParams P, const int
                 const double bwv = P.bw[node];
                 bar = (bwv == 0.0) ? 0.0 : bwv * F;
             } else {
-                bar = P.invn * F;
+                bar = (P.invn == 0.0) ? 0.0 : P.invn * F;   // invn == 0: linear part only (c_dot_Dz)
             }
             double lin = 0.0;
 #pragma unroll

@@ -217,7 +217,7 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     P->d_scratch.alloc((size_t)reduce_scratch_doubles(std::max<int64_t>(mmax, (int64_t)zn)));
     P->d_nodeF.alloc((size_t)P->n);
     P->d_x.alloc(mmax); P->d_g.alloc(mmax); P->d_nv.alloc(mmax); P->d_xn.alloc(mmax);
-    P->d_gn.alloc(mmax); P->d_tmp.alloc(mmax);
+    P->d_gn.alloc(mmax); P->d_tmp.alloc(std::max<size_t>(mmax, zn));   // d_tmp also holds the t-ramp's roll-back copy of z
     {
         size_t tch = 1;
         for (auto& L : P->levels) tch = std::max(tch, (size_t)L.T_chunks * (size_t)L.m);

@@ -393,3 +393,167 @@ def test_config2_size_properties_and_determinism():
     zb = sol1.z[:, 0]
     bnd = np.array([v + e * 7 for (v, e) in m.find_boundary(prob.geometry)])
     assert np.abs(zb[bnd] - prob.g[bnd, 0]).max() < 1e-12                    # Dirichlet data preserved exactly
+
+
+# ---- functor branches the default problems never reach (reference: src/convex_euclidian_power.jl:18-36,
+# :352-453: general per-node A, non-zero b, per-node p(x); src/convex_piecewise.jl:15-75: a genuine
+# spatial select mask incl. the -Inf slack rule) --------------------------------------------------
+
+def _same_iteration_counts(a, b):
+    """Identical Newton counts on every t-step but the last: the finalize pass stops on the exact rule
+    `ynext >= ymin` (src/newton.jl:187), which sits at rounding level and may differ by a step or two."""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and np.array_equal(a[:, :-1], b[:, :-1])
+    assert np.abs(a[:, -1] - b[:, -1]).max() <= 3
+
+
+def _general_ep(mg, dim):
+    """Per-node SPD A(x) (nz x nz, column-major flattened), non-zero b(x), p(x) sweeping [1, 4]."""
+    nz = dim + 1
+    def A(x):
+        t = np.sin(3.0 * x[0] + 2.0 * x[-1])
+        S = np.zeros((nz, nz))
+        for i in range(nz):
+            for j in range(i):
+                S[i, j] = S[j, i] = (0.25 if max(i, j) < nz - 1 else 0.0005) * np.cos((i + 1) * (j + 2) * x[0] + t)
+        return np.eye(nz) * (1.0 + 0.3 * t) + S + 0.4 * np.eye(nz)
+    def b(x):
+        return np.array([0.1 * np.sin(2 * x[0] + k) for k in range(nz - 1)] + [1.0 + x[0] ** 2])
+    p = lambda x: 2.5 + 1.5 * np.sin(4.0 * x[0] - 3.0 * x[-1])                    # in [1, 4]
+    return m.convex_Euclidian_power(mg, idx=tuple(range(2, dim + 3)), A=A, b=b, p=p)
+
+
+@pytest.mark.parametrize("kind", ["fem2d_P2", "fem3d", "fem1d"])
+def test_ep_general_A_b_and_per_node_p_match_oracle(kind):
+    if kind == "fem2d_P2":
+        mg, dim = m.amg(m.subdivide(m.fem2d_P2(), 3)), 2
+    elif kind == "fem3d":
+        mg, dim = m.amg(m.subdivide(m.fem3d(k=1), 2)), 3
+    else:
+        mg, dim = m.amg(m.fem1d(nodes=np.linspace(-1, 1, 17))), 1
+    Q = _general_ep(mg, dim)
+    pc = Q.pieces[0]
+    assert np.unique(pc.p).size >= 8 and pc.p.min() < 1.3 and pc.p.max() > 3.7     # genuinely per node
+    assert set(np.unique(pc.mu)) == {1.0, 2.0} and np.count_nonzero(pc.b) > 0.75 * pc.b.size
+    x = mg.geometry.xflat
+    g_grid = np.stack([0.25 * np.sum(x ** 2, axis=1), np.full(x.shape[0], 1000.0)], axis=1)
+    prob = m.assemble(mg, Q=Q, g_grid=g_grid)
+    D = _device(prob)
+    try:
+        Mo = O.OracleAMG(prob.M[0])
+        z0 = stacked(prob.g)
+        assert np.all(np.isfinite(O.convex_eval(Q, O.apply_D(Mo.D_fine, z0), 0)))
+        _check_primitives(D.main, Mo, prob.Q, 0.1 * prob.f, z0, np.random.default_rng(11), scale=1e-3)
+        # cobarrier image of the same cone (phase-I wrapper), general A / b / p
+        nD = len(prob.M[0].D_fine)
+        n = x.shape[0]
+        feas = D.feasibility
+        feas.set_box(2000.0, 3000.0)
+        z1 = np.concatenate([z0, np.full(n, 5.0)])
+        c1 = np.zeros((n, nD + 1 + 2)); c1[:, nD] = 1.0
+        _check_primitives(feas, O.OracleAMG(prob.M[1]), O.FeasConvex(prob.Q, 2000.0, 3000.0, nD + 1), c1, z1,
+                          np.random.default_rng(12), scale=1e-4)
+    finally:
+        D.close()
+    # end to end, same problem: device vs oracle (reference cross-backend bar, test/test_cuda.jl:51)
+    sol = m.mgb_solve(prob)
+    ref = O.mgb_solve(prob)
+    assert np.abs(sol.z - ref["z"]).max() < 1e-8
+    _same_iteration_counts(sol.SOL_main["its"], ref["SOL_main"]["its"])
+
+
+def _select_problem(with_gap):
+    """Region-dependent constraints (the docstring example of src/convex_piecewise.jl:105-111 plus a
+    linear piece): piece 0 = EP(p = 1.5) where x < 0.25, piece 1 = EP(p = 3) where x > -0.25 (both in the
+    middle strip), piece 2 = the box -1 < u < 2 on y > 0 only.  with_gap: no piece at all on x > 0.6."""
+    mg = m.amg(m.subdivide(m.fem2d_P2(), 3))
+    n = mg.geometry.w.size
+    Q0 = m.convex_Euclidian_power(mg, idx=(2, 3, 4), p_grid=np.full(n, 1.5))
+    Q1 = m.convex_Euclidian_power(mg, idx=(2, 3, 4), p_grid=np.full(n, 3.0))
+    Q2 = m.convex_linear(mg, idx=(1,), A=lambda x: np.array([[1.0], [-1.0]]), b=lambda x: np.array([1.0, 2.0 + 0.1 * x[1]]))
+    def select(x):
+        if with_gap and x[0] > 0.6:
+            return (0.0, 0.0, 0.0)
+        return (float(x[0] < 0.25), float(x[0] > -0.25), float(x[1] > 0.0))
+    Q = m.convex_piecewise(mg, (Q0, Q1, Q2), select=select)
+    return mg, Q
+
+
+@pytest.mark.parametrize("with_gap", [False, True])
+def test_piecewise_select_mask_matches_oracle(with_gap):
+    mg, Q = _select_problem(with_gap)
+    assert Q.select is not None
+    act = Q.select != 0
+    assert act[:, 0].any() and (~act[:, 0]).any() and (act[:, 0] & act[:, 1]).any() and (~act[:, 2]).any()
+    assert (~act.any(axis=1)).any() == with_gap
+    prob = m.assemble(mg, Q=Q)
+    D = _device(prob)
+    try:
+        Mo = O.OracleAMG(prob.M[0])
+        z0 = stacked(prob.g)
+        rng = np.random.default_rng(21)
+        _check_primitives(D.main, Mo, prob.Q, 0.1 * prob.f, z0, rng, scale=1e-3, solve=not with_gap)   # gap: H_ss = 0 there
+        Dz = O.apply_D(Mo.D_fine, z0)
+        F_d = D.main.node_barrier(z0)
+        F_o = O.convex_eval(Q, Dz, 0)
+        assert rel(F_d, F_o) <= 1e-12
+        assert np.all(F_d[~act.any(axis=1)] == 0.0)              # no active piece: exact zero, never 0 * Inf
+        s_d, s_o = D.main.node_slack(z0), O.convex_slack(Q, Dz)
+        fin = np.isfinite(s_o)
+        assert np.array_equal(np.isneginf(s_d), np.isneginf(s_o))    # typemin where nothing is active
+        assert np.isneginf(s_o).any() == with_gap
+        assert rel(s_d[fin], s_o[fin]) <= 1e-12
+        # an infeasible point for piece 1 only: the slack is the max over the ACTIVE pieces
+        zbad = z0.copy(); zbad[prob.g.shape[0]:] = 5.0           # s = 5 violates s^(2/3) > |grad u|^2 near the corners
+        Dzb = O.apply_D(Mo.D_fine, zbad)
+        sb_d, sb_o = D.main.node_slack(zbad), O.convex_slack(Q, Dzb)
+        finb = np.isfinite(sb_o)
+        assert (sb_o[finb] > 0).any() and rel(sb_d[finb], sb_o[finb]) <= 1e-12
+        # phase-I image (cobarriers of the selected pieces + box)
+        n, nD = prob.g.shape[0], len(prob.M[0].D_fine)
+        feas = D.feasibility
+        feas.set_box(300.0, 400.0)
+        z1 = np.concatenate([z0, np.full(n, 3.0)])
+        c1 = np.zeros((n, nD + 1 + 2)); c1[:, nD] = 1.0
+        _check_primitives(feas, O.OracleAMG(prob.M[1]), O.FeasConvex(prob.Q, 300.0, 400.0, nD + 1), c1, z1, rng, scale=1e-4)
+    finally:
+        D.close()
+    if not with_gap:     # with a gap the slack is unbounded below there: no central path (reference semantics)
+        sol = m.mgb_solve(prob)
+        ref = O.mgb_solve(prob)
+        assert np.abs(sol.z - ref["z"]).max() < 1e-8
+        _same_iteration_counts(sol.SOL_main["its"], ref["SOL_main"]["its"])
+
+
+def test_c_dot_Dz_diagnostic_matches_oracle():
+    # SOL_main.c_dot_Dz uses the UNSCALED cost grid (reference: src/mgb.jl:135-136, :165-166)
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 3)), p=1.5)
+    sol = m.mgb_solve(prob)
+    ref = O.mgb_solve(prob)
+    a, b = np.asarray(sol.SOL_main["c_dot_Dz"]), np.asarray(ref["SOL_main"]["c_dot_Dz"])
+    assert a.shape == b.shape and np.allclose(a, b, rtol=1e-9, atol=1e-12)
+    Mo = O.OracleAMG(prob.M[0])
+    Dz = O.apply_D(Mo.D_fine, stacked(sol.z))
+    assert np.isclose(a[-1], float(np.sum(Mo.w[:, None] * prob.f * Dz)), rtol=1e-10)
+
+
+def test_default_hierarchy_initial_centring_at_L8_is_pinned():
+    """The reference-default ladder `amg_ruge_stuben(max_coarse=2)` coarsens the P1 corner problem to
+    1-4 unknowns.  With this package's Ruge-Stueben restatement the p = 1 solve converges on it at
+    L = 8, while for p = 1.5 the initial centring stalls in the 4-unknown space (Newton creeps along the
+    barrier wall until lambda^2 <= 0).  Device and oracle must agree on both outcomes; DESIGN.md
+    section 6 records the evidence and why the P entries of the third-party AMG are unpinned."""
+    from mgb_amd.solve import MGBConvergenceFailure
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 8)), p=1.5)
+    assert [R.shape[1] for R in prob.M[0].R_fine][:3] == [4, 15, 66]
+    with pytest.raises(MGBConvergenceFailure) as ed:
+        m.mgb_solve(prob)
+    assert ed.value.code == "stall" and "Initial centering failed" in str(ed.value)
+    st = {}
+    with pytest.raises(O.MGBConvergenceFailure) as eo:
+        O.mgb_solve(prob, stats=st)
+    assert eo.value.code == "stall" and "Initial centering failed" in str(eo.value)
+    # the smallest deviation that converges: max_coarse = 10 (coarsest space 15 unknowns)
+    prob10 = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 8), prolongator=m.amg_ruge_stuben(max_coarse=10)), p=1.5)
+    sol = m.mgb_solve(prob10)
+    assert np.isfinite(sol.z).all() and int(sol.SOL_main["its"].sum()) < 400

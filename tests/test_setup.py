@@ -132,3 +132,58 @@ def test_find_boundary_counts():
     assert len(m.find_boundary(m.spectral2d(n=4))) == 4 * 4 - (4 - 2) ** 2
     g = m.fem3d(k=2)
     assert len(m.find_boundary(g)) == g.x.shape[0] * g.x.shape[1] - 1
+
+
+# ---- Ruge-Stueben restatement (reference: src/amg_prolongators.jl:16-18 -> AlgebraicMultigrid.jl) ----
+
+def _laplace_5pt(nx, neumann=True):
+    ex = sp.diags([-np.ones(nx - 1), -np.ones(nx - 1)], [-1, 1])
+    A = sp.kron(sp.identity(nx), ex) + sp.kron(ex, sp.identity(nx))
+    A = sp.csr_matrix(A)
+    d = -np.asarray(A.sum(axis=1)).ravel()
+    return sp.csr_matrix(A + sp.diags(d if neumann else np.full(nx * nx, 4.0)))
+
+
+def test_rs_splitting_red_black_on_the_five_point_stencil():
+    from mgb_amd import amg_prolongators as ap
+    nx = 9
+    A = _laplace_5pt(nx)
+    S = ap._classical_strength(A, 0.25)
+    assert (S != (A - sp.diags(A.diagonal())).astype(bool)).nnz == 0      # every neighbour is strong
+    is_c = ap._rs_cf_splitting(S)
+    # first-pass RS on the 5-point stencil is the red-black colouring: no two C points are
+    # neighbours and every F point has a C neighbour
+    C = sp.diags(is_c.astype(float))
+    assert (C @ S @ C).nnz == 0
+    assert np.all((S @ is_c.astype(float))[~is_c] > 0)
+    ij = np.add.outer(np.arange(nx), np.arange(nx)).ravel() % 2
+    assert np.array_equal(is_c, ij == ij[is_c.argmax()])
+    # the first C point is the top of the last bucket: largest lambda, highest node index
+    lam = np.asarray(S.sum(axis=0)).ravel()
+    assert is_c[np.flatnonzero(lam == lam.max()).max()]
+    # direct interpolation of a zero-row-sum matrix reproduces constants
+    P = ap._direct_interpolation(A, S, is_c)
+    assert np.allclose(P @ np.ones(P.shape[1]), 1.0, atol=1e-14)
+    assert np.array_equal(np.asarray(P[is_c].todense()), np.eye(int(is_c.sum())))
+
+
+def test_rs_nodes_nobody_depends_on_are_f_points():
+    from mgb_amd import amg_prolongators as ap
+    # node 3 depends on node 2 (one-sided strength: |a_32| is large in row 3, tiny in row 2)
+    A = sp.csr_matrix(np.array([[2.0, -1.0, 0.0, 0.0], [-1.0, 2.0, -1.0, 0.0], [0.0, -1.0, 2.0, -0.1],
+                                [0.0, 0.0, -0.1, 2.0]]))
+    S = ap._classical_strength(A, 0.25)
+    assert S[2, 3] == 0 and S[3, 2] != 0
+    is_c = ap._rs_cf_splitting(S)
+    assert not is_c[3]                                  # lambda(3) = 0: an F point from the start
+    assert ap.ruge_stuben_prolongations(sp.identity(5, format="csr"), max_coarse=2) == []
+
+
+def test_rs_level_sizes_of_the_baseline_meshes():
+    # regression pin of the default `amg_ruge_stuben(max_coarse=2)` ladder (max_levels = 10 caps L = 9)
+    sizes = {}
+    for L in (5, 7):
+        mg = m.amg(m.subdivide(m.fem2d_P2(), L))
+        sizes[L] = ([R.shape[1] for R in mg.R["full"]], [R.shape[1] for R in mg.R["dirichlet"]])
+    assert sizes[5] == ([1, 3, 9, 36, 144, 289, 3584], [1, 7, 28, 112, 225, 1473, 1473])
+    assert sizes[7] == ([1, 4, 11, 37, 138, 543, 2113, 4225, 57344], [1, 8, 33, 126, 509, 1985, 3969, 24321, 24321])
