@@ -99,6 +99,12 @@ typedef struct {
     const mgbhip_csr* R;          /* L prolongations, coarsest first                      */
     mgbhip_cone cone;
     const double* barrier_weights;/* n, or NULL for the flat (1/n) average (src/convex.jl:279-304) */
+    /* Node coordinates `AMG.x` (src/multigrid.jl:280), n x dim column-major, or NULL.  Used only as an
+     * ordering hint by the sparse direct solve (geometric nested dissection on the centroids of the
+     * level-J basis functions); NULL falls back to a graph-only dissection.  Results do not depend
+     * on it beyond rounding. */
+    const double* x;
+    int32_t dim;
 } mgbhip_problem_desc;
 
 /* Solver controls (reference defaults: src/mgb.jl:95-101, :360-363, src/newton.jl:139). */

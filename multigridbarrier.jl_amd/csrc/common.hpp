@@ -110,18 +110,22 @@ struct StageTimers {
         MGB_HIP_CHECK(hipEventCreate(&e));
         return e;
     }
+    std::vector<size_t> open;      // indices into `pending` of the scopes not yet closed (they nest)
     void begin(const char* name) {
         if (!enabled) return;
         Pending p{name, get(), get()};
         MGB_HIP_CHECK(hipEventRecord(p.a, stream));
         pending.push_back(p);
+        open.push_back(pending.size() - 1);
     }
     void end() {
-        if (!enabled) return;
-        MGB_HIP_CHECK(hipEventRecord(pending.back().b, stream));
-        if (pending.size() > 4096) collect();
+        if (!enabled || open.empty()) return;
+        MGB_HIP_CHECK(hipEventRecord(pending[open.back()].b, stream));
+        open.pop_back();
+        if (open.empty() && pending.size() > 4096) collect();
     }
     void collect() {
+        if (!open.empty()) return;         // a scope is still running: its end event does not exist yet
         for (auto& p : pending) {
             MGB_HIP_CHECK(hipEventSynchronize(p.b));
             float ms = 0;

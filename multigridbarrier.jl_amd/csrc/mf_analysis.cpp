@@ -36,6 +36,8 @@ struct Builder {
     std::vector<int32_t> tag;       // subset membership id
     std::vector<int32_t> lvl;       // BFS level
     int32_t next_tag = 1;
+    const double* coords = nullptr; // optional n x dim locations (geometric dissection)
+    int dim = 0;
 
     void new_supernode(const int32_t* nodes, size_t cnt) {
         int32_t s = (int32_t)sn_piv.size();
@@ -146,11 +148,66 @@ struct Builder {
         }
     }
 
+    // Geometric bisection: cut the longest axis of the bounding box at the median coordinate.  B is
+    // the side at or above the cut; the separator is the layer of B that touches A (on a mesh whose
+    // nodes sit on the cut line this is exactly that line).  Returns false when the cut degenerates.
+    bool dissect_geometric(std::vector<int32_t>& nodes) {
+        const size_t cnt = nodes.size();
+        int axis = 0;
+        double best_ext = -1.0;
+        for (int d = 0; d < dim; ++d) {
+            double lo = 1e300, hi = -1e300;
+            for (int32_t v : nodes) {
+                const double c = coords[(size_t)v * dim + d];
+                lo = std::min(lo, c);
+                hi = std::max(hi, c);
+            }
+            if (hi - lo > best_ext) { best_ext = hi - lo; axis = d; }
+        }
+        if (!(best_ext > 0)) return false;
+        std::vector<int32_t> sorted(nodes);
+        auto key = [&](int32_t v) { return coords[(size_t)v * dim + axis]; };
+        std::nth_element(sorted.begin(), sorted.begin() + cnt / 2, sorted.end(),
+                         [&](int32_t a, int32_t b) { const double ka = key(a), kb = key(b); return ka < kb || (ka == kb && a < b); });
+        const double thr = key(sorted[cnt / 2]);
+        const int32_t id = next_tag++;
+        size_t nA = 0;
+        for (int32_t v : nodes) {
+            const bool inA = key(v) < thr;
+            tag[v] = inA ? id : -id;          // A: +id, B: -id
+            nA += inA;
+        }
+        if (nA == 0 || nA == cnt) return false;
+        std::vector<int32_t> A, B, S;
+        A.reserve(nA);
+        for (int32_t v : nodes) {
+            if (tag[v] == id) { A.push_back(v); continue; }
+            bool touches = false;
+            for (int32_t e = g.ptr[v]; e < g.ptr[v + 1] && !touches; ++e) touches = tag[g.idx[e]] == id;
+            (touches ? S : B).push_back(v);
+        }
+        if (S.empty()) {                      // the two sides are not connected at all: no separator
+            nodes.clear();
+            nodes.shrink_to_fit();
+            dissect(A);
+            dissect(B);
+            return true;
+        }
+        if (B.empty() || S.size() * 3 > cnt) return false;     // a thick cut: let the graph method try
+        nodes.clear();
+        nodes.shrink_to_fit();
+        dissect(A);
+        dissect(B);
+        new_supernode(S.data(), S.size());
+        return true;
+    }
+
     void dissect(std::vector<int32_t>& nodes) {
         if ((int32_t)nodes.size() <= opt.leaf_size) {
             if (!nodes.empty()) new_supernode(nodes.data(), nodes.size());
             return;
         }
+        if (coords && dim > 0 && dissect_geometric(nodes)) return;
         int32_t id = next_tag++;
         for (int32_t v : nodes) tag[v] = id;
         std::vector<int32_t> order;
@@ -224,7 +281,7 @@ struct Builder {
 }  // namespace
 
 void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const MfOptions& opt,
-                MfPlan& plan) {
+                MfPlan& plan, const double* coords, int dim) {
     plan = MfPlan();
     plan.n = n;
     if (n == 0) { plan.level_ptr.assign(1, 0); return; }
@@ -235,6 +292,8 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
     b.removed.assign(n, 0);
     b.tag.assign(n, 0);
     b.lvl.assign(n, 0);
+    b.coords = coords;
+    b.dim = dim;
 
     b.peel(plan);
     {
@@ -288,6 +347,10 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
             const int64_t merged_m = ks + (int64_t)b.sn_piv[f].size() + (int64_t)sn_struct[f].size();
             const bool relaxed = opt.merge_max_m > 0 && merged_m <= opt.merge_max_m;
             if (!exact && !relaxed) continue;
+            // an exact fit costs no flops, but merging a large child serialises two pivot chains that
+            // the tree would run side by side (the half-domain separator into the root separator):
+            // only fronts that stay within one LDS workgroup are amalgamated
+            if (!relaxed && merged_m > opt.exact_merge_max_m) continue;
             if (!relaxed) {
                 if ((int64_t)extra_piv[f] * ks > 64) continue;          // zeros between merged siblings
                 if (ks + (int64_t)b.sn_piv[f].size() > 64 && extra_piv[f] > 0) continue;

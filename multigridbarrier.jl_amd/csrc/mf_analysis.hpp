@@ -9,8 +9,9 @@
 //      clique (zero fill).  On the fine level this removes the broken slack DoFs
 //      (H_ss is diagonal because D_s = id) and then the element bubbles, i.e. the
 //      classical FEM static condensation, discovered from the graph alone;
-//   2. nested dissection of the rest by BFS level-set bisection with separator
-//      trimming; leaves of <= leaf_size nodes;
+//   2. nested dissection of the rest: geometric (coordinate-median cuts, separator = the
+//      boundary layer of one side) when the caller knows where the unknowns live, else BFS
+//      level-set bisection with separator trimming; leaves of <= leaf_size nodes;
 //   3. supernodal symbolic factorization on that partition (exact row structures),
 //      exact-fit amalgamation of a child into its parent, relative index maps,
 //      level schedule (leaves first).
@@ -61,12 +62,15 @@ struct MfOptions {
     int32_t peel_max_degree = 48;
     double sep_weight = 1.5;      // separator-size penalty in the bisection score
     int32_t merge_max_m = 0;      // relaxed amalgamation: merge a child into its parent while m stays <= this
+    int32_t exact_merge_max_m = 128;  // exact-fit amalgamation only while the merged front stays this small
 };
 
 // Symmetric pattern in CSR (both triangles present, diagonal optional).  Values are not
 // needed: the plan records, for every structural pair {v,u}, the CSR position of the
 // entry in the upper triangle (row <= col), which is what `symmetric(H)` reads.
+// coords (optional): n x dim row-major locations of the unknowns; when given, the dissection cuts
+// the longest axis of each subset's bounding box at the median (straight separators on meshes).
 void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const MfOptions& opt,
-                MfPlan& plan);
+                MfPlan& plan, const double* coords = nullptr, int dim = 0);
 
 }  // namespace mgbhip

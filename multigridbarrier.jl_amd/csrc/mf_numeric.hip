@@ -1100,13 +1100,15 @@ __global__ __launch_bounds__(BIG1_THREADS) void mf_bwd_big1(const FrontDev* __re
 
 }  // namespace
 
-void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st) {
+void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st,
+                       const double* coords, int dim) {
     MfOptions opt;
     // tuning overrides (defaults are the measured best on MI355X)
     if (const char* e = getenv("MGBHIP_LEAF")) opt.leaf_size = atoi(e);
     if (const char* e = getenv("MGBHIP_SEPW")) opt.sep_weight = atof(e);
     if (const char* e = getenv("MGBHIP_MERGE")) opt.merge_max_m = atoi(e);
-    mf_analyze(n, rowptr, colidx, opt, plan);
+    if (const char* e = getenv("MGBHIP_NO_GEO"); e && e[0] == '1') coords = nullptr;
+    mf_analyze(n, rowptr, colidx, opt, plan, coords, dim);
     const int32_t nf = (int32_t)plan.fronts.size();
     std::vector<FrontDev> fd(nf);
     for (int32_t i = 0; i < nf; ++i) {
@@ -1210,11 +1212,21 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
 }
 
 
+// per-tree-level stage timers (MGBHIP_LEVEL_TIMING=1): "fac_lvNN", "fwd_lvNN", "bwd_lvNN"
+static StageTimers g_dummy_timers;
+static StageTimers* timers_or_dummy(StageTimers* t, bool on) { return (t && on) ? t : &g_dummy_timers; }
+
 void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timers) {
     MGB_REQUIRE(analyzed, "MfSolver::factor before analyze");
     if (timers) timers->begin("factor");
     d_status.zero(st);
-    for (auto& lev : level_launches)
+    static const bool lvl_timing = [] { const char* e = getenv("MGBHIP_LEVEL_TIMING"); return e && e[0] == '1'; }();
+    int lvno = -1;
+    for (auto& lev : level_launches) {
+        ++lvno;
+        char nm[32];
+        snprintf(nm, sizeof(nm), "fac_lv%02d", lvno);
+        StageScope lvscope(*timers_or_dummy(timers, lvl_timing), nm);
         for (auto& L : lev) {
             if (L.count == 0) continue;
             if (L.tiny) {
@@ -1253,6 +1265,7 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 }
             }
         }
+    }
     MGB_HIP_CHECK(hipGetLastError());
     if (timers) timers->end();
 }
@@ -1260,7 +1273,13 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
 void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers* timers) {
     MGB_REQUIRE(analyzed, "MfSolver::solve before analyze");
     if (timers) timers->begin("trisolve");
-    for (auto& lev : level_solves)
+    static const bool lvl_timing = [] { const char* e = getenv("MGBHIP_LEVEL_TIMING"); return e && e[0] == '1'; }();
+    int lvno = -1;
+    for (auto& lev : level_solves) {
+        ++lvno;
+        char nm[32];
+        snprintf(nm, sizeof(nm), "fwd_lv%02d", lvno);
+        StageScope lvscope(*timers_or_dummy(timers, lvl_timing), nm);
         for (auto& L : lev) {
             if (L.count == 0) continue;
             if (L.tiny) {
@@ -1289,7 +1308,11 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
                                    d_arena.p, d_tbig.p, d_tsol.p, d_y.p, d_uvec.p);
             }
         }
-    for (int32_t l = (int32_t)level_solves.size() - 1; l >= 0; --l)
+    }
+    for (int32_t l = (int32_t)level_solves.size() - 1; l >= 0; --l) {
+        char nm[32];
+        snprintf(nm, sizeof(nm), "bwd_lv%02d", l);
+        StageScope lvscope(*timers_or_dummy(timers, lvl_timing), nm);
         for (auto it = level_solves[l].rbegin(); it != level_solves[l].rend(); ++it) {
             const MfLaunch& L = *it;
             if (L.count == 0) continue;
@@ -1315,6 +1338,7 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
                 }
             }
         }
+    }
     MGB_HIP_CHECK(hipGetLastError());
     if (timers) timers->end();
 }

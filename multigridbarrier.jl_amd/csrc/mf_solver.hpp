@@ -25,7 +25,9 @@ struct MfLaunch {          // one kernel launch: a contiguous range of fronts of
 class MfSolver {
    public:
     MfPlan plan;
-    void analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st);
+    // coords (optional): n x dim row-major locations of the unknowns, an ordering hint (mf_analysis.hpp)
+    void analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st,
+                 const double* coords = nullptr, int dim = 0);
     // factor the matrix whose CSR values (same pattern as analyze) live at d_values.
     // Asynchronous; the not-SPD flag is read back by status().
     void factor(const double* d_values, hipStream_t st, StageTimers* timers);

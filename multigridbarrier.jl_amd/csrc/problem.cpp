@@ -91,6 +91,10 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     P->nu = d->nu;
     P->nD = d->nD;
     P->dense = d->p > 64;
+    if (d->x && d->dim > 0 && d->dim <= 3 && !P->dense) {
+        P->hx.assign(d->x, d->x + (size_t)d->dim * P->n);
+        P->xdim = d->dim;
+    }
     MGB_REQUIRE((int64_t)P->nu * P->n < INT32_MAX, "problem too large for 32-bit row indices");
     hipStream_t st = ctx->stream;
     const size_t blk = (size_t)d->p * d->p * d->N;
@@ -696,7 +700,24 @@ void mgbhip_problem::factor(int level) {
     hipStream_t st = stream();
     if (!L.solver.analyzed) {
         const auto t0 = std::chrono::steady_clock::now();
-        L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st);
+        // ordering hint: the centroid of every level-J basis function, sum_i |R_ij| x_i / sum_i |R_ij|
+        std::vector<double> cen;
+        if (!hx.empty() && xdim > 0 && !L.hRptr.empty()) {
+            cen.assign((size_t)L.m * xdim, 0.0);
+            std::vector<double> wsum((size_t)L.m, 0.0);
+            for (int64_t r = 0; r < L.rows; ++r) {
+                const int64_t node = r % n;
+                for (int32_t q = L.hRptr[r]; q < L.hRptr[r + 1]; ++q) {
+                    const double a = std::fabs(L.hRval[q]);
+                    const int32_t j = L.hRcol[q];
+                    wsum[j] += a;
+                    for (int d = 0; d < xdim; ++d) cen[(size_t)j * xdim + d] += a * hx[(size_t)d * n + node];
+                }
+            }
+            for (int64_t j = 0; j < L.m; ++j)
+                for (int d = 0; d < xdim; ++d) cen[(size_t)j * xdim + d] = wsum[j] > 0 ? cen[(size_t)j * xdim + d] / wsum[j] : 0.0;
+        }
+        L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st, cen.empty() ? nullptr : cen.data(), xdim);
         if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
             fprintf(stderr, "[mgbhip] symbolic analysis level %d (m=%lld, nnz=%lld): %.2f s\n", level, (long long)L.m,
                     (long long)L.nnz, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());

@@ -76,6 +76,8 @@ struct mgbhip_problem {
     mgbhip::DevBuf<double> bw;
     bool has_bw = false;
     std::vector<mgbhip::Level> levels;
+    std::vector<double> hx;                // host copy of the node coordinates (n x dim, column-major) or empty
+    int32_t xdim = 0;
     // workspace
     mgbhip::DevBuf<double> d_z, d_z0, d_zfull, d_c, d_ret, d_hel, d_partials, d_scal, d_scratch, d_nodeF, d_nodeDz, d_dnDz, d_dnY, d_tchunk;
     mgbhip::DevBuf<double> d_x, d_g, d_nv, d_xn, d_gn, d_tmp, d_c0;

@@ -78,7 +78,7 @@ class _Desc(C.Structure):
     _fields_ = [("p", C.c_int32), ("N", C.c_int64), ("nu", C.c_int32), ("nD", C.c_int32), ("n_ops", C.c_int32),
                 ("ops", _dp * MAX_OPS), ("D_state", C.c_int32 * MAX_ND), ("D_op", C.c_int32 * MAX_ND),
                 ("w", _dp), ("L", C.c_int32), ("R", C.POINTER(_CSR)), ("cone", _Cone),
-                ("barrier_weights", _dp)]
+                ("barrier_weights", _dp), ("x", _dp), ("dim", C.c_int32)]
 
 
 class Options(C.Structure):
@@ -291,6 +291,9 @@ class DeviceProblem:
                     P.mu = grid(pc.mu, 1)
             if Q.select is not None:
                 P.select = grid(Q.select[:, k], 1)
+        xc = np.asfortranarray(np.asarray(M.x, dtype=np.float64).reshape(self.n, -1))     # AMG.x, ordering hint
+        keep.append(xc)
+        d.x, d.dim = _ptr(xc), xc.shape[1]
         bw = None
         if barrier_weights is not None:
             bw = _f64(barrier_weights)
