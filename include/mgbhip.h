@@ -121,6 +121,17 @@ typedef struct {
     int32_t finalize;             /* 1: stopping_exact(finalize_theta); 0: NoFinalize */
     double finalize_theta;        /* 0.9 */
     int32_t early_stop;           /* 0 none; 1 phase-I margin rule (src/mgb.jl:486-491)   */
+    /* Optional user callables, NULL = the built-in rule selected above.  They receive only what the
+     * reference hands to the corresponding Julia callable:
+     *   stopping_criterion(ymin, ynext, gmin, |gnext|, sqrt(incmin), sqrt(inc)): the reference's
+     *   `stop(ymin, ynext, gmin, gnext, n, ndecmin, ndec)` (src/newton.jl:187,222-225,279; kwarg of mgb_solve,
+     *   src/mgb.jl:360) with the vectors gnext, n reduced to the norm both built-in rules use -> non-zero = converged;
+     *   early_stop(z, t): z is the current fine iterate copied to the host (nu*n doubles), called
+     *   between completed t-steps like `early_stop(z)` (src/mgb.jl:85-89,138) -> non-zero = stop.  */
+    int (*stopping_criterion)(double ymin, double ynext, double gmin, double gnorm_next, double ndecmin, double ndec,
+                              void* user);
+    int (*early_stop_fn)(const double* z, double t, void* user);
+    void* user;
 } mgbhip_options;
 
 /* Diagnostics of one mgb_core run (the fields of SOL_main, src/mgb.jl:176-182). */
@@ -184,6 +195,37 @@ int mgbhip_mgb_core(mgbhip_problem* prob, double* z /* nu*n in/out */, const dou
 int mgbhip_matched_t(mgbhip_problem* prob, const double* z, const double* c, double t_default,
                      double* t_out);
 void mgbhip_default_options(mgbhip_options* opt, int64_t n_nodes);
+
+/* ---- device-resident vectors and closures ------------------------------------------------------
+ * The "fine" integration style of SURVEY.md section 8b: a binding that keeps the reference's generic
+ * `newton` / `mgb_step` (src/newton.jl:227-287, src/mgb.jl:16-82) wraps `mgbhip_vec` in its device
+ * vector type; nothing crosses PCIe per call except scalars.  A vector belongs to one context and is
+ * used on that context's stream.  (The CUDA extension gets these from CuArray broadcasting:
+ * ext/MultiGridBarrierCUDAExt/mgb_interface.jl:14-41.)                                           */
+typedef struct mgbhip_vec mgbhip_vec;
+int mgbhip_vec_alloc(mgbhip_ctx* ctx, int64_t len, mgbhip_vec** out);      /* mgb_zeros: zero-filled  */
+int mgbhip_vec_free(mgbhip_vec* v);
+int64_t mgbhip_vec_len(const mgbhip_vec* v);
+int mgbhip_vec_upload(mgbhip_vec* v, const double* host, int64_t len);
+int mgbhip_vec_download(const mgbhip_vec* v, double* host, int64_t len);
+int mgbhip_vec_fill(mgbhip_vec* v, double value);
+int mgbhip_vec_copy(mgbhip_vec* dst, const mgbhip_vec* src);
+int mgbhip_vec_axpy(double alpha, const mgbhip_vec* x, mgbhip_vec* y);      /* y += alpha x            */
+int mgbhip_vec_scale(double alpha, mgbhip_vec* x);                          /* x *= alpha              */
+int mgbhip_vec_dot(const mgbhip_vec* a, const mgbhip_vec* b, double* out);
+int mgbhip_vec_norm(const mgbhip_vec* a, double* out);                      /* 2-norm                  */
+int mgbhip_vec_isfinite(const mgbhip_vec* a, int32_t* all_finite);          /* mgb_all_isfinite        */
+/* The Barrier closures and the direct solve on device vectors (s: m_J, c: n*nD column-major,
+ * z0: nu*n, grad/x: m_J); f2_d leaves H assembled on the device for solve_d.                     */
+int mgbhip_f0_d(mgbhip_problem* prob, int32_t level, const mgbhip_vec* s, const mgbhip_vec* c,
+                const mgbhip_vec* z0, double* value);
+int mgbhip_f1_d(mgbhip_problem* prob, int32_t level, const mgbhip_vec* s, const mgbhip_vec* c,
+                const mgbhip_vec* z0, mgbhip_vec* grad);
+int mgbhip_f2_d(mgbhip_problem* prob, int32_t level, const mgbhip_vec* s, const mgbhip_vec* c,
+                const mgbhip_vec* z0);
+int mgbhip_solve_d(mgbhip_problem* prob, int32_t level, const mgbhip_vec* g, mgbhip_vec* x);
+/* z += R_J s  (src/mgb.jl:60) */
+int mgbhip_prolong_add(mgbhip_problem* prob, int32_t level, const mgbhip_vec* s, mgbhip_vec* z);
 
 /* ---- measurement hooks (bench.py): device-time of the named stage of the last call,
  * from hipEvents on the handle's stream.                                               */

@@ -3,7 +3,9 @@
 // the CPU: a missing / failing GPU is an error, never a fallback.
 #include <cmath>
 #include <cstring>
+#include <algorithm>
 #include <limits>
+#include <memory>
 #include <string>
 
 #include "problem.hpp"
@@ -13,6 +15,10 @@ using namespace mgbhip;
 mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mgbhip_problem* share);
 int core_run(mgbhip_problem* P, double* z, const double* c, const mgbhip_options* opt, mgbhip_core_result* res);
 int matched_t_run(mgbhip_problem* P, const double* z, const double* c, double t_default, double* t_out);
+
+#ifdef MGB_STEP_PROBE
+namespace mgbhip { void mf_debug_probe(long long* out64); }
+#endif
 
 static thread_local std::string g_last_error;
 
@@ -33,6 +39,7 @@ struct DeviceGuard {
 };
 static int dev_of(const mgbhip_ctx* c) { return c ? c->device : -1; }
 static int dev_of(const mgbhip_problem* p) { return (p && p->ctx) ? p->ctx->device : -1; }
+static int dev_of(const mgbhip_vec* v) { return (v && v->ctx) ? v->ctx->device : -1; }
 
 #define MGB_API_BEGIN try {
 #define MGB_API_BEGIN_ON(h) try { DeviceGuard _guard(dev_of(h));
@@ -211,6 +218,205 @@ int mgbhip_solve(mgbhip_problem* P, int32_t level, const double* g, double* x) {
     MGB_API_END
 }
 
+
+// ---- device-resident vectors --------------------------------------------------------------------
+static double* vec_scratch(mgbhip_ctx* c, int64_t len) {
+    c->vscratch.ensure((size_t)reduce_scratch_doubles(len));
+    c->vscal.ensure(8);
+    return c->vscratch.p;
+}
+static void same_ctx(const mgbhip_vec* a, const mgbhip_vec* b) {
+    MGB_REQUIRE(a && b, "null vector");
+    MGB_REQUIRE(a->ctx == b->ctx, "vectors belong to different contexts");
+}
+
+int mgbhip_vec_alloc(mgbhip_ctx* ctx, int64_t len, mgbhip_vec** out) {
+    MGB_API_BEGIN_ON(ctx)
+    MGB_REQUIRE(ctx && out && len >= 0, "bad argument");
+    std::unique_ptr<mgbhip_vec> v(new mgbhip_vec());
+    v->ctx = ctx;
+    v->len = len;
+    v->buf.alloc((size_t)std::max<int64_t>(len, 1));
+    v->buf.zero(ctx->stream);
+    *out = v.release();
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_vec_free(mgbhip_vec* v) {
+    MGB_API_BEGIN_ON(v)
+    if (!v) return MGBHIP_OK;
+    (void)hipStreamSynchronize(v->ctx->stream);
+    delete v;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int64_t mgbhip_vec_len(const mgbhip_vec* v) { return v ? v->len : -1; }
+
+int mgbhip_vec_upload(mgbhip_vec* v, const double* host, int64_t len) {
+    MGB_API_BEGIN_ON(v)
+    MGB_REQUIRE(v && host && len == v->len, "upload: length mismatch");
+    v->buf.upload(host, (size_t)len, v->ctx->stream);
+    MGB_HIP_CHECK(hipStreamSynchronize(v->ctx->stream));     // the host buffer may go away
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_vec_download(const mgbhip_vec* v, double* host, int64_t len) {
+    MGB_API_BEGIN_ON(v)
+    MGB_REQUIRE(v && host && len == v->len, "download: length mismatch");
+    v->buf.download(host, (size_t)len, v->ctx->stream);
+    MGB_HIP_CHECK(hipStreamSynchronize(v->ctx->stream));
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_vec_fill(mgbhip_vec* v, double value) {
+    MGB_API_BEGIN_ON(v)
+    MGB_REQUIRE(v, "null vector");
+    launch_fill(value, v->buf.p, v->len, v->ctx->stream);
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_vec_copy(mgbhip_vec* dst, const mgbhip_vec* src) {
+    MGB_API_BEGIN_ON(dst)
+    same_ctx(dst, src);
+    MGB_REQUIRE(dst->len == src->len, "copy: length mismatch");
+    if (dst->len) MGB_HIP_CHECK(hipMemcpyAsync(dst->buf.p, src->buf.p, (size_t)dst->len * sizeof(double),
+                                               hipMemcpyDeviceToDevice, dst->ctx->stream));
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_vec_axpy(double alpha, const mgbhip_vec* x, mgbhip_vec* y) {
+    MGB_API_BEGIN_ON(y)
+    same_ctx(x, y);
+    MGB_REQUIRE(x->len == y->len, "axpy: length mismatch");
+    if (y->len) launch_axpy(alpha, x->buf.p, y->buf.p, y->len, y->ctx->stream);
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_vec_scale(double alpha, mgbhip_vec* x) {
+    MGB_API_BEGIN_ON(x)
+    MGB_REQUIRE(x, "null vector");
+    if (x->len) launch_scale_copy(x->buf.p, alpha, x->buf.p, x->len, x->ctx->stream);
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_vec_dot(const mgbhip_vec* a, const mgbhip_vec* b, double* out) {
+    MGB_API_BEGIN_ON(a)
+    same_ctx(a, b);
+    MGB_REQUIRE(out && a->len == b->len, "dot: bad argument");
+    *out = 0.0;
+    if (a->len == 0) return MGBHIP_OK;
+    mgbhip_ctx* c = a->ctx;
+    double* sc = vec_scratch(c, a->len);
+    launch_dot(a->buf.p, b->buf.p, a->len, sc, c->vscal.p, c->stream);
+    c->vscal.download(out, 1, c->stream);
+    MGB_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+static int vec_stats_host(const mgbhip_vec* a, double* two) {
+    mgbhip_ctx* c = a->ctx;
+    two[0] = two[1] = 0.0;
+    if (a->len == 0) return MGBHIP_OK;
+    double* sc = vec_scratch(c, a->len);
+    launch_vec_stats(a->buf.p, a->len, sc, c->vscal.p, c->stream);
+    c->vscal.download(two, 2, c->stream);
+    MGB_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MGBHIP_OK;
+}
+
+int mgbhip_vec_norm(const mgbhip_vec* a, double* out) {
+    MGB_API_BEGIN_ON(a)
+    MGB_REQUIRE(a && out, "null argument");
+    double two[2];
+    vec_stats_host(a, two);
+    *out = std::sqrt(two[0]);
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_vec_isfinite(const mgbhip_vec* a, int32_t* all_finite) {
+    MGB_API_BEGIN_ON(a)
+    MGB_REQUIRE(a && all_finite, "null argument");
+    double two[2];
+    vec_stats_host(a, two);
+    *all_finite = (two[1] == 0.0) ? 1 : 0;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+static void check_closure_args(mgbhip_problem* P, int32_t level, const mgbhip_vec* s, const mgbhip_vec* c, const mgbhip_vec* z0) {
+    check_level(P, level);
+    MGB_REQUIRE(s && c && z0, "null vector");
+    MGB_REQUIRE(s->ctx == P->ctx && c->ctx == P->ctx && z0->ctx == P->ctx, "vector and problem belong to different contexts");
+    MGB_REQUIRE(s->len == P->levels[level].m, "s has the wrong length for this level");
+    MGB_REQUIRE(c->len == P->n * P->nD, "c must hold n x nD entries");
+    MGB_REQUIRE(z0->len == (int64_t)P->nu * P->n, "z0 must hold nu x n entries");
+}
+
+int mgbhip_f0_d(mgbhip_problem* P, int32_t level, const mgbhip_vec* s, const mgbhip_vec* c, const mgbhip_vec* z0, double* value) {
+    MGB_API_BEGIN_ON(P)
+    check_closure_args(P, level, s, c, z0);
+    MGB_REQUIRE(value, "null argument");
+    P->touch();                           // caller-owned vectors: no cached z0 + R*s can be trusted
+    *value = P->eval_f0(level, s->buf.p, z0->buf.p, c->buf.p);
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_f1_d(mgbhip_problem* P, int32_t level, const mgbhip_vec* s, const mgbhip_vec* c, const mgbhip_vec* z0, mgbhip_vec* grad) {
+    MGB_API_BEGIN_ON(P)
+    check_closure_args(P, level, s, c, z0);
+    MGB_REQUIRE(grad && grad->ctx == P->ctx && grad->len == s->len, "grad has the wrong length");
+    P->touch();
+    P->eval_f1(level, s->buf.p, z0->buf.p, c->buf.p, grad->buf.p);
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_f2_d(mgbhip_problem* P, int32_t level, const mgbhip_vec* s, const mgbhip_vec* c, const mgbhip_vec* z0) {
+    MGB_API_BEGIN_ON(P)
+    check_closure_args(P, level, s, c, z0);
+    P->touch();
+    P->eval_f2(level, s->buf.p, z0->buf.p, c->buf.p);
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_solve_d(mgbhip_problem* P, int32_t level, const mgbhip_vec* g, mgbhip_vec* x) {
+    MGB_API_BEGIN_ON(P)
+    check_level(P, level);
+    MGB_REQUIRE(g && x && g->ctx == P->ctx && x->ctx == P->ctx, "bad vector");
+    MGB_REQUIRE(g->len == P->levels[level].m && x->len == g->len, "solve: length mismatch");
+    hipStream_t st = P->stream();
+    P->factor(level);
+    P->trisolve(level, g->buf.p, x->buf.p);
+    const int status = P->levels[level].solver.status(st);
+    if (status != MGBHIP_OK) g_last_error = "Cholesky met a non-positive pivot";
+    return status;
+    MGB_API_END
+}
+
+int mgbhip_prolong_add(mgbhip_problem* P, int32_t level, const mgbhip_vec* s, mgbhip_vec* z) {
+    MGB_API_BEGIN_ON(P)
+    check_level(P, level);
+    MGB_REQUIRE(s && z && s->ctx == P->ctx && z->ctx == P->ctx, "bad vector");
+    const Level& Lv = P->levels[level];
+    MGB_REQUIRE(s->len == Lv.m && z->len == Lv.rows, "prolong_add: length mismatch");
+    launch_csr_matvec(Lv.rows, Lv.Rptr.p, Lv.Rcol.p, Lv.Rval.p, s->buf.p, z->buf.p, true, false, P->stream());
+    P->touch();
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
 static int node_map(mgbhip_problem* P, const double* z, double* F, double* Dz, int mode) {
     MGB_REQUIRE(P && z && F, "null argument");
     hipStream_t st = P->stream();
@@ -254,6 +460,9 @@ void mgbhip_default_options(mgbhip_options* o, int64_t n_nodes) {
     o->finalize = 1;
     o->finalize_theta = 0.9;
     o->early_stop = 0;
+    o->stopping_criterion = nullptr;
+    o->early_stop_fn = nullptr;
+    o->user = nullptr;
 }
 
 int mgbhip_mgb_core(mgbhip_problem* P, double* z, const double* c, const mgbhip_options* opt, mgbhip_core_result* res) {
@@ -303,6 +512,10 @@ int mgbhip_solver_stats(mgbhip_problem* P, int32_t level, double* out) {
     return MGBHIP_OK;
     MGB_API_END
 }
+
+#ifdef MGB_STEP_PROBE
+int mgbhip_debug_probe(long long* out64) { (void)hipDeviceSynchronize(); mgbhip::mf_debug_probe(out64); return 0; }
+#endif
 
 int mgbhip_reset_stage_timers(mgbhip_problem* P, int enable) {
     MGB_API_BEGIN_ON(P)

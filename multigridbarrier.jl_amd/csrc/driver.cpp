@@ -27,10 +27,13 @@ bool debug_on() {
 }
 #define DBG(...) do { if (debug_on()) { fprintf(stderr, __VA_ARGS__); } } while (0)
 
-struct Stop {       // stopping_exact / stopping_inexact
+struct Stop {       // stopping_exact / stopping_inexact, or the caller's own rule
     double lambda_tol;   // < 0: exact only
     double theta;
-    bool operator()(double ymin, double ynext, double gmin, double gnorm_next, double ndec) const {
+    int (*fn)(double, double, double, double, double, double, void*) = nullptr;
+    void* user = nullptr;
+    bool operator()(double ymin, double ynext, double gmin, double gnorm_next, double ndecmin, double ndec) const {
+        if (fn) return fn(ymin, ynext, gmin, gnorm_next, ndecmin, ndec, user) != 0;
         const bool exact = (ynext >= ymin) && (gnorm_next >= theta * gmin);
         if (lambda_tol >= 0) return (ndec < lambda_tol) || exact;
         return exact;
@@ -222,7 +225,7 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
             ynext = y;
             gnorm_next = gnorm;
         }
-        if (stop(ymin, ynext, gmin, gnorm_next, std::sqrt(inc))) converged = true;
+        if (stop(ymin, ynext, gmin, gnorm_next, std::sqrt(incmin), std::sqrt(inc))) converged = true;
         if (moved) {
             std::swap(P->d_x, P->d_xn);
             std::swap(P->d_g, P->d_gn);
@@ -253,7 +256,7 @@ StepResult mgb_step(mgbhip_problem* P, const double* d_c, const mgbhip_options& 
     StepResult out;
     out.its.assign(L, 0);
     hipStream_t st = P->stream();
-    const Stop sc{opt.stop_lambda_tol, opt.stop_theta};
+    const Stop sc{opt.stop_lambda_tol, opt.stop_theta, opt.stopping_criterion, opt.user};
     const Stop fin{-1.0, opt.finalize_theta};
     const size_t zn = (size_t)P->nu * P->n;
     auto eta = [&](int j, int J, const Stop& stop, int maxit) -> bool {
@@ -334,7 +337,14 @@ int core_run(mgbhip_problem* P, double* z, const double* c, const mgbhip_options
     int k = 1;
     std::vector<double> hbuf;
     double t_first = INFINITY;
+    std::vector<double> zhost;
     auto early = [&](double tt) -> bool {
+        if (opt.early_stop_fn) {                           // user `early_stop(z)` / `early_stop(z, t)` (src/mgb.jl:85-89)
+            zhost.resize(zn);
+            P->d_z.download(zhost.data(), zn, st);
+            MGB_HIP_CHECK(hipStreamSynchronize(st));
+            if (opt.early_stop_fn(zhost.data(), tt, opt.user) != 0) return true;
+        }
         if (opt.early_stop != 1) return false;
         if (!slack_feasible(P, hbuf)) return false;        // margin rule (src/mgb.jl:486-491)
         t_first = std::fmin(t_first, tt);

@@ -578,6 +578,11 @@ __global__ __launch_bounds__(256) void axpy_kernel(double alpha, const double* _
     if (i < len) y[i] += alpha * x[i];
 }
 
+__global__ __launch_bounds__(256) void fill_kernel(double value, double* __restrict__ y, int64_t len) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < len) y[i] = value;
+}
+
 // ---- assembly ------------------------------------------------------------------------------------
 
 // Row-owner gather: every structural nonzero of R'HR sums its contributions from the
@@ -1076,6 +1081,12 @@ void launch_scale_copy(const double* src, double alpha, double* dst, int64_t len
 void launch_axpy(double alpha, const double* x, double* y, int64_t len, hipStream_t st) {
     if (len == 0) return;
     hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, alpha, x, y, len);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_fill(double value, double* y, int64_t len, hipStream_t st) {
+    if (len == 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, value, y, len);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

@@ -74,6 +74,7 @@ void launch_step(const double* x, const double* n, double s, double* xn, int64_t
                  hipStream_t st);
 void launch_scale_copy(const double* src, double alpha, double* dst, int64_t len, hipStream_t st);
 void launch_axpy(double alpha, const double* x, double* y, int64_t len, hipStream_t st);
+void launch_fill(double value, double* y, int64_t len, hipStream_t st);       // y[:] = value
 
 // selection levels: H[q] = sum_{t in contributions(q)} slab[cidx[t]]
 void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,

@@ -98,6 +98,79 @@ __device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NBT], int nb, int lan
     return bad;
 }
 
+// Same factorization with the pivot chain software-pipelined: column j+1 is updated first and its
+// reciprocal pivot is started before the bulk of column j's updates, so the long rcp + Newton
+// latency hides behind the broadcast/FMA stream instead of standing between two columns.
+template <int NBT>
+__device__ __forceinline__ bool wave_ldlt_pipe(double (&a)[NBT], int nb, int lane) {
+    bool bad = false;
+    double d = readlane_f64(a[0], 0);
+    if (d == 0.0 || !isfinite(d)) bad = true;
+    double inv = fast_recip(d);
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+        if (j < nb) {
+            const double aj = a[j];
+            const double lr = aj * inv;
+            double inv_next = 1.0;
+            if (j + 1 < NBT) {
+                a[j + 1] -= lr * readlane_f64(aj, j + 1);
+                if (j + 1 < nb) {
+                    const double dn = readlane_f64(a[j + 1], j + 1);
+                    if (dn == 0.0 || !isfinite(dn)) bad = true;
+                    inv_next = fast_recip(dn);
+                }
+            }
+#pragma unroll
+            for (int c = j + 2; c < NBT; ++c) a[c] -= lr * readlane_f64(aj, c);
+            if (lane > j) a[j] = lr;
+            inv = inv_next;
+        }
+    }
+    return bad;
+}
+
+// LDL' of a 32 x 32 block by one wave with the multiplier columns broadcast through LDS instead of
+// v_readlane (a readlane + dependent FMA pair costs ~35 cycles on gfx950; a broadcast ds_read_b128
+// delivers two multipliers per issue slot).  Lane r (and its twin r + 32) holds row r in registers.
+// Column j+1 is brought up to date first, published to the other LDS buffer and its reciprocal pivot
+// started, then the remaining columns take the rank-1 update of column j: the pivot chain and the
+// LDS round trip hide behind the bulk FMAs.  colbuf: 2 x 32 doubles, 16-byte aligned.
+__device__ __forceinline__ bool wave_ldlt_lds32(double (&a)[NB], int nb, int lane, double* colbuf) {
+    bool bad = false;
+    const int r = lane & 31;
+    if (lane < 32) colbuf[r] = a[0];
+    double d = readlane_f64(a[0], 0);
+    if (d == 0.0 || !isfinite(d)) bad = true;
+    double inv = fast_recip(d);
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (j < nb) {
+            const double* cb = colbuf + 32 * (j & 1);
+            double* cn = colbuf + 32 * ((j + 1) & 1);
+            const double aj = a[j];
+            const double lr = aj * inv;
+            double inv_next = 1.0;
+            if (j + 1 < NB) {
+                a[j + 1] -= lr * cb[j + 1];
+                if (lane < 32) cn[r] = a[j + 1];
+                if (j + 1 < nb) {
+                    const double dn = readlane_f64(a[j + 1], j + 1);
+                    if (dn == 0.0 || !isfinite(dn)) bad = true;
+                    inv_next = fast_recip(dn);
+                }
+            }
+#pragma unroll
+            for (int c = j + 2; c < NB; ++c) a[c] -= lr * cb[c];
+            if (r > j) a[j] = lr;
+            inv = inv_next;
+            wave_sync();
+        }
+    }
+    return bad;
+}
+
 // One workgroup per front.  Right-looking LDL' blocked by NB = 32 columns: wave 0 factors the
 // diagonal block in registers (shuffles only), every thread then solves one panel row in
 // registers, and all threads apply the rank-32 update -- 3 workgroup barriers per 32 columns.
@@ -1098,6 +1171,478 @@ __global__ __launch_bounds__(BIG1_THREADS) void mf_bwd_big1(const FrontDev* __re
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// large fronts, inverse-based path (fronts with 128 < m <= BIG_INV_MAX_M)
+// ------------------------------------------------------------------------------------------------
+// One launch per 32-column step.  The diagonal block of step j is factored AND inverted ahead of
+// time by the look-ahead workgroup of step j-1 (W_j = L_jj^{-1}, d_j); every trailing tile then
+// forms the two panel slices it needs by a small matrix-core product with W_j,
+//     S = A21 W_j'  (= L21 D),   L = S D^{-1},
+// instead of waiting for a separate triangular-solve kernel, and applies  C -= S L'  on the matrix
+// cores (v_mfma_f64_16x16x4_f64).  The panel itself is never written back: the arena keeps the
+// fully updated, UNSOLVED rows A21 and the triangular solves apply W_j / d_j on the fly
+// (L21 y = A21 (W_j' D^{-1} y)).  Home layout of a factored diagonal block: strictly UPPER triangle
+// = W_j transposed (entry (c, q), c < q, holds W_j[q][c]); the pivots d_j live in `dvec`; the lower
+// triangle keeps the unfactored block (sibling workgroups of step 0 still read it).
+constexpr int BIG_INV_MAX_M = 7000;     // work vectors of the single-workgroup solves stay in LDS
+constexpr int BIGI_THREADS = 1024;
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// Wave 0 only (rows on lanes 0..31): LDL' of the nb x nb lower block in Dn (row-major [r][c]).  On
+// return Dn holds the strictly lower unit factor L (zero elsewhere, identity rows beyond nb) and
+// dq the pivots (1 beyond nb).
+__device__ __forceinline__ void wave_ldlt_lds(double (*Dn)[NB + 1], double* dq, int nb, int lane,
+                                              int32_t* __restrict__ status, double* colbuf) {
+    double d[NB];
+    const int rl = lane & 31;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) d[c] = (rl < nb && c <= rl) ? Dn[rl][c] : 0.0;
+    const bool bad = wave_ldlt_lds32(d, nb, lane, colbuf);
+    if (bad && lane == 0 && status) atomicOr(status, 1);
+    if (lane < NB) {
+        double piv = 1.0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            Dn[lane][c] = (c < lane && lane < nb) ? d[c] : 0.0;
+            if (c == lane && lane < nb) piv = d[c];
+        }
+        dq[lane] = piv;
+    }
+}
+
+// W = L^{-1} for the unit lower triangular 32 x 32 L in Ls (strictly lower part, row-major), all 256
+// threads: 4 x 4 diagonal blocks in closed form, then three doubling steps
+//   W21 = -W22 (L21 W11)
+// through a 16 x 16 temporary.  Wv receives W with unit diagonal and a zero upper triangle.
+// Every thread of the workgroup must call this (7 barriers).
+__device__ __forceinline__ void block_inverse32(const double (*Ls)[NB + 1], double (*Wv)[NB + 1], double (*Tm)[17],
+                                                int tid) {
+    for (int i = tid; i < NB * NB; i += 256) Wv[i / NB][i % NB] = (i / NB == i % NB) ? 1.0 : 0.0;
+    __syncthreads();
+    if (tid < NB / 4) {
+        const int o = 4 * tid;
+        const double l21 = Ls[o + 1][o], l31 = Ls[o + 2][o], l32 = Ls[o + 2][o + 1];
+        const double l41 = Ls[o + 3][o], l42 = Ls[o + 3][o + 1], l43 = Ls[o + 3][o + 2];
+        Wv[o + 1][o] = -l21;
+        Wv[o + 2][o + 1] = -l32;
+        Wv[o + 3][o + 2] = -l43;
+        Wv[o + 2][o] = l32 * l21 - l31;
+        Wv[o + 3][o + 1] = l43 * l32 - l42;
+        Wv[o + 3][o] = l42 * l21 + l43 * (l31 - l32 * l21) - l41;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 4; s < NB; s *= 2) {
+        const int ss = s * s;
+        const bool on = tid < 16 * s;
+        const int pr = tid / ss, e = tid % ss, i = e % s, j = e / s;
+        const int base = 2 * s * pr;
+        if (on) {       // structural zeros (W11 upper, W22 upper) make the fixed trip count exact
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int a = 0; a < s; a += 2) {
+                t0 += Ls[base + s + i][base + a] * Wv[base + a][base + j];
+                t1 += Ls[base + s + i][base + a + 1] * Wv[base + a + 1][base + j];
+            }
+            Tm[pr * s + i][j] = t0 + t1;
+        }
+        __syncthreads();
+        if (on) {
+            double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+            for (int a = 0; a < s; a += 2) {
+                w0 += Wv[base + s + i][base + s + a] * Tm[pr * s + a][j];
+                w1 += Wv[base + s + i][base + s + a + 1] * Tm[pr * s + a + 1][j];
+            }
+            Wv[base + s + i][base + j] = -(w0 + w1);
+        }
+        __syncthreads();
+    }
+}
+
+// S = A W' for a 64-row slice held raw in P[c][rr] (LDS, overwritten in place); wave w owns rows
+// 16w .. 16w+15, so no cross-wave hazard.  scale != nullptr: result columns are multiplied by
+// scale[q] (the reciprocal pivots) and written to Pout (may alias P).
+__device__ __forceinline__ void slice_transform(double (*P)[ST + 1], double (*Pout)[ST + 1], double (*P2)[ST + 1],
+                                                const double (*Wv)[NB + 1], const double* rd, int lane, int wave) {
+    const int fr = lane & 15, fk = lane >> 4;
+    const int rr = 16 * wave + fr;
+    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const double a = P[4 * kk + fk][rr];                       // y[k][j]: A[rr = j][c = k]
+        if (kk < 4) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wv[fr][4 * kk + fk], a, acc0, 0, 0, 0);   // q tile 0: c < 16 only
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wv[16 + fr][4 * kk + fk], a, acc1, 0, 0, 0);
+    }
+    // D[i][j]: i = fk + 4 reg -> q within the tile, j = fr -> rr
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q0 = fk + 4 * r, q1 = 16 + fk + 4 * r;
+        Pout[q0][rr] = acc0[r];
+        Pout[q1][rr] = acc1[r];
+        if (P2) {
+            P2[q0][rr] = acc0[r] * rd[q0];
+            P2[q1][rr] = acc1[r] * rd[q1];
+        }
+    }
+}
+
+#ifdef MGB_STEP_PROBE
+__device__ long long g_probe[64];
+#define PROBE(i) do { if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[i] = wall_clock64(); if (!is_la && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[16 + i] = wall_clock64(); } while (0)
+#else
+#define PROBE(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ fr, int32_t first, int j0,
+                                                   double* __restrict__ arena, double* __restrict__ dscr,
+                                                   double* __restrict__ dvec, int32_t* __restrict__ status,
+                                                   int do_diag) {
+    __shared__ double Wv[NB][NB + 1];
+    __shared__ double Dn[NB][NB + 1];
+    __shared__ double Tm[16][17];
+    __shared__ double dq[NB], rdq[NB];
+    __shared__ __attribute__((aligned(16))) double colbuf[2 * NB];
+    __shared__ double Pa[NB][ST + 1];
+    __shared__ double Pb[NB][ST + 1];
+    const FrontDev F = fr[first + blockIdx.y];
+    const int m = F.m, k = F.k;
+    if (j0 >= k) return;
+    const int nb = min(NB, k - j0);
+    const int j1 = j0 + nb;
+    const int T = (m - j1 + ST - 1) / ST;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* W = arena + F.F_off;
+    double* slot = dscr + ((int64_t)blockIdx.y * 2 + ((j0 / NB) & 1)) * (NB * NB);
+    const bool is_la = blockIdx.x == gridDim.x - 1;
+    int ti = 0, tj = 0;
+    if (!is_la) {
+        const int lin = blockIdx.x;
+        ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+        while (ti * (ti + 1) / 2 > lin) --ti;
+        tj = lin - ti * (ti + 1) / 2;
+        if (ti >= T) return;
+    }
+    const bool look = j1 < k;
+    const int nbn = look ? min(NB, k - j1) : 0;
+    const int rbase = is_la ? j1 : j1 + ti * ST, cbase = j1 + tj * ST;
+    PROBE(0);
+    const int fr16 = lane & 15, fk = lane >> 4;
+
+    // ---- global loads first: raw panel slices and this wave's part of the C tile -----------------
+    double pa[NB * ST / 256], pb[NB * ST / 256];
+#pragma unroll
+    for (int u = 0; u < NB * ST / 256; ++u) {
+        const int i = tid + 256 * u, rr = i % ST, q = i / ST;
+        const int r = rbase + rr, c = cbase + rr;
+        const bool rin = is_la ? (rr < nbn) : (r < m);
+        pa[u] = (q < nb && rin) ? W[r + (int64_t)(j0 + q) * m] : 0.0;
+        pb[u] = (!is_la && ti != tj && q < nb && c < m) ? W[c + (int64_t)(j0 + q) * m] : 0.0;
+    }
+    double cw[4][4];
+    if (!is_la) {
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rbase + 16 * wave + fr16, col = cbase + 16 * tb + fk + 4 * r;
+                cw[tb][r] = (row < m && col < m && row >= col) ? W[row + (int64_t)col * m] : 0.0;
+            }
+    } else {
+        // corner of the next diagonal block, entry (rr, c) per thread x 4
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = tid + 256 * t, rr = i % NB, c = i / NB;
+            cw[0][t] = (look && rr >= c && rr < nbn) ? W[(j1 + rr) + (int64_t)(j1 + c) * m] : 0.0;
+        }
+    }
+    // ---- W_j, d_j ----------------------------------------------------------------------------------
+    if (do_diag) {
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int rr = i % NB, c = i / NB;
+            Dn[rr][c] = (rr >= c && rr < nb) ? W[(j0 + rr) + (int64_t)(j0 + c) * m] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 64) wave_ldlt_lds(Dn, dq, nb, tid, is_la ? status : nullptr, colbuf);
+        __syncthreads();
+        block_inverse32(Dn, Wv, Tm, tid);
+    } else {
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int rr = i % NB, c = i / NB;
+            const double v = (rr >= c && rr < nb) ? slot[rr + NB * c] : 0.0;
+            Wv[rr][c] = (rr > c) ? v : (rr == c ? 1.0 : 0.0);
+            if (rr == c) dq[rr] = (rr < nb) ? v : 1.0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NB * ST / 256; ++u) {
+        const int i = tid + 256 * u, rr = i % ST, q = i / ST;
+        Pa[q][rr] = pa[u];
+        Pb[q][rr] = pb[u];
+    }
+    __syncthreads();
+    PROBE(1);
+    if (tid < NB) rdq[tid] = 1.0 / dq[tid];
+    if (is_la) {
+        // home of block j: strictly upper triangle = W_j', pivots to dvec (nobody reads either during this step)
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int q = i % NB, c = i / NB;          // entry (c, q), c < q
+            if (c < q && q < nb) W[(j0 + c) + (int64_t)(j0 + q) * m] = Wv[q][c];
+        }
+        if (tid < nb) dvec[F.idx_off + j0 + tid] = dq[tid];
+        if (!look) return;
+    }
+    __syncthreads();
+    PROBE(2);
+    // ---- S (into Pa) and L (into Pb) ---------------------------------------------------------------
+    if (is_la) {
+        if (wave < 2) slice_transform(Pa, Pa, Pb, Wv, rdq, lane, wave);     // 32 rows of the next block
+        __syncthreads();
+        PROBE(3);
+        {   // D_{j+1} = corner - S L' on the matrix cores: wave w -> (row tile w & 1, column tile w >> 1)
+            const int rt = wave & 1, ct = wave >> 1;
+            double4_t accd = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < NB / 4; ++kk)
+                accd = __builtin_amdgcn_mfma_f64_16x16x4f64(Pb[4 * kk + fk][16 * ct + fr16], Pa[4 * kk + fk][16 * rt + fr16],
+                                                            accd, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * rt + fr16, c = 16 * ct + fk + 4 * r;
+                Dn[rr][c] = -accd[r];        // the corner entries are added by their loader threads below
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = tid + 256 * t, rr = i % NB, c = i / NB;
+            Dn[rr][c] = (rr >= c && rr < nbn) ? cw[0][t] + Dn[rr][c] : 0.0;
+        }
+        __syncthreads();
+        double* nslot = dscr + ((int64_t)blockIdx.y * 2 + ((j1 / NB) & 1)) * (NB * NB);
+        PROBE(4);
+#ifdef MGB_STEP_PROBE
+        if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[32] = clock64();
+#endif
+        if (tid < 64) wave_ldlt_lds(Dn, dq, nbn, tid, status, colbuf);
+#ifdef MGB_STEP_PROBE
+        if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[33] = clock64();
+#endif
+        __syncthreads();
+        PROBE(5);
+        block_inverse32(Dn, Wv, Tm, tid);
+        PROBE(6);
+        for (int i = tid; i < NB * NB; i += 256) {        // slot: diagonal d, strictly lower W (column-major)
+            const int rr = i % NB, c = i / NB;
+            if (rr >= c && rr < nbn) nslot[rr + NB * c] = (rr == c) ? dq[rr] : Wv[rr][c];
+        }
+        PROBE(7);
+        return;
+    }
+    if (ti == tj) {
+        slice_transform(Pa, Pa, Pb, Wv, rdq, lane, wave);
+    } else {
+        slice_transform(Pa, Pa, nullptr, Wv, rdq, lane, wave);
+        // the column-side slice: L = (A W') D^{-1}
+        {
+            const int rr = 16 * wave + fr16;
+            double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < NB / 4; ++kk) {
+                const double a = Pb[4 * kk + fk][rr];
+                if (kk < 4) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wv[fr16][4 * kk + fk], a, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wv[16 + fr16][4 * kk + fk], a, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q0 = fk + 4 * r, q1 = 16 + fk + 4 * r;
+                Pb[q0][rr] = acc0[r] * rdq[q0];
+                Pb[q1][rr] = acc1[r] * rdq[q1];
+            }
+        }
+    }
+    __syncthreads();
+    PROBE(3);
+    // ---- C -= S L' : wave w owns rows 16w..16w+15, four 16-column tiles ---------------------------
+    double4_t acc[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) acc[tb] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const double s = Pa[4 * kk + fk][16 * wave + fr16];            // y[k][j]: S[rr = j][q = k]
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+            if (ti == tj && tb > wave) continue;                          // strictly above the diagonal
+            acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pb[4 * kk + fk][16 * tb + fr16], s, acc[tb], 0, 0, 0);
+        }
+    }
+    const int nskip = (blockIdx.x == 0 && look) ? nbn : 0;               // corner owned by the look-ahead workgroup
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rbase + 16 * wave + fr16, col = cbase + 16 * tb + fk + 4 * r;
+            if (row < m && col < m && row >= col && !(row - j1 < nskip && col - j1 < nskip))
+                W[row + (int64_t)col * m] = cw[tb][r] - acc[tb][r];
+        }
+    PROBE(4);
+}
+
+// ---- triangular solves on the inverse-based layout: one workgroup per front --------------------
+// forward:  y' = L^{-1} t by blocks:  y'_j = W_j t_j,  u = W_j' D_j^{-1} y'_j,  t[r] -= A[r, j] u  (r below)
+__global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __restrict__ fr, int32_t first,
+                                                           const int32_t* __restrict__ front_idx,
+                                                           const int32_t* __restrict__ children,
+                                                           const int32_t* __restrict__ rel,
+                                                           const double* __restrict__ arena,
+                                                           const double* __restrict__ dvec,
+                                                           const double* __restrict__ b, double* __restrict__ y,
+                                                           double* __restrict__ uvec) {
+    extern __shared__ double sh[];
+    const FrontDev F = fr[first + blockIdx.x];
+    const int m = F.m, k = F.k;
+    const int tid = threadIdx.x, nt = BIGI_THREADS;
+    double* tl = sh;                               // [m]
+    double* Wl = sh + ((m + 1) & ~1);              // [NB][NB + 1]
+    double* dl = Wl + NB * (NB + 1);               // [NB]
+    double* uq = dl + NB;                          // [NB]
+    const int32_t* idx = front_idx + F.idx_off;
+    const double* Fm = arena + F.F_off;
+    const double* dv = dvec + F.idx_off;
+    for (int j = tid; j < m; j += nt) tl[j] = (j < k) ? b[idx[j]] : 0.0;
+    __syncthreads();
+    for (int c = 0; c < F.nchild; ++c) {
+        const FrontDev C = fr[children[F.child_off + c]];
+        const int32_t* rl = rel + C.rel_off;
+        const double* uc = uvec + C.u_off;
+        const int bc = C.m - C.k;
+        for (int j = tid; j < bc; j += nt) tl[rl[j]] += uc[j];
+        __syncthreads();
+    }
+    const int wa = tid % NB, wb = tid / NB;          // W_j[q = wb][c = wa] sits at (j0 + wa, j0 + wb), wa < wb
+    double wnext = (wa < wb && wb < k) ? Fm[wa + (int64_t)wb * m] : 0.0;
+    for (int j0 = 0; j0 < k; j0 += NB) {
+        const int nb = min(NB, k - j0), j1 = j0 + nb;
+        Wl[wb * (NB + 1) + wa] = (wa < wb) ? wnext : (wa == wb ? 1.0 : 0.0);
+        if (tid < NB) dl[tid] = (tid < nb) ? dv[j0 + tid] : 1.0;
+        __syncthreads();
+        {
+            const int jn = j0 + NB;
+            wnext = (wa < wb && jn + wb < k) ? Fm[(jn + wa) + (int64_t)(jn + wb) * m] : 0.0;
+        }
+        if (tid < 64) {
+            const int q = tid & 31;
+            double v = 0.0;
+            if (q < nb)
+                for (int c = 0; c <= q; ++c) v += Wl[q * (NB + 1) + c] * tl[j0 + c];
+            wave_sync();
+            if (tid < nb) tl[j0 + tid] = v;                       // y'_j
+            const double vs = (q < nb) ? v / dl[q] : 0.0;
+            uq[q] = vs;                                           // both half-waves write the same values
+            wave_sync();
+            double u = 0.0;
+            if (q < nb)
+                for (int qq = q; qq < nb; ++qq) u += Wl[qq * (NB + 1) + q] * uq[qq];
+            wave_sync();
+            if (tid < NB) uq[tid] = (tid < nb) ? u : 0.0;
+        }
+        __syncthreads();
+        for (int r = j1 + tid; r < m; r += nt) {
+            const double* Ar = Fm + r + (int64_t)j0 * m;
+            double v = 0.0;
+            if (nb == NB) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) v += Ar[(int64_t)c * m] * uq[c];
+            } else {
+                for (int c = 0; c < nb; ++c) v += Ar[(int64_t)c * m] * uq[c];
+            }
+            tl[r] -= v;
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < m; j += nt) {
+        if (j < k) y[idx[j]] = tl[j] / dv[j];
+        else uvec[F.u_off + j - k] = tl[j];
+    }
+}
+
+// backward:  x_j = W_j' ( y_j - D_j^{-1} W_j G_j ),  G[q] = sum over solved rows r of A[r, q] x[r]
+__global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __restrict__ fr, int32_t first,
+                                                           const int32_t* __restrict__ front_idx,
+                                                           const double* __restrict__ arena,
+                                                           const double* __restrict__ dvec,
+                                                           const double* __restrict__ y, double* __restrict__ x) {
+    extern __shared__ double sh[];
+    const FrontDev F = fr[first + blockIdx.x];
+    const int m = F.m, k = F.k;
+    const int tid = threadIdx.x, nt = BIGI_THREADS;
+    const int lane = tid & 63, wave = tid >> 6;
+    double* tl = sh;                               // [m]: y on the pivots (then x), x(boundary) below
+    double* gl = sh + ((m + 1) & ~1);              // [k]
+    double* Wl = gl + ((k + 1) & ~1);              // [NB][NB + 1]
+    double* dl = Wl + NB * (NB + 1);
+    double* zq = dl + NB;
+    const int32_t* idx = front_idx + F.idx_off;
+    const double* Fm = arena + F.F_off;
+    const double* dv = dvec + F.idx_off;
+    for (int j = tid; j < m; j += nt) tl[j] = (j < k) ? y[idx[j]] : x[idx[j]];
+    __syncthreads();
+    for (int q = wave; q < k; q += nt / 64) {      // boundary rows: one wave per pivot column, coalesced along rows
+        const double* Aq = Fm + (int64_t)q * m;
+        double s = 0.0;
+        for (int r = k + lane; r < m; r += 64) s += Aq[r] * tl[r];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) gl[q] = s;
+    }
+    const int wa = tid % NB, wb = tid / NB;
+    const int last = ((k - 1) / NB) * NB;
+    double wnext = (wa < wb && last + wb < k) ? Fm[(last + wa) + (int64_t)(last + wb) * m] : 0.0;
+    __syncthreads();
+    for (int j0 = last; j0 >= 0; j0 -= NB) {
+        const int nb = min(NB, k - j0);
+        Wl[wb * (NB + 1) + wa] = (wa < wb) ? wnext : (wa == wb ? 1.0 : 0.0);
+        if (tid < NB) dl[tid] = (tid < nb) ? dv[j0 + tid] : 1.0;
+        __syncthreads();
+        if (j0 >= NB) {
+            const int jn = j0 - NB;
+            wnext = (wa < wb) ? Fm[(jn + wa) + (int64_t)(jn + wb) * m] : 0.0;
+        }
+        if (tid < 64) {
+            const int q = tid & 31;
+            double h = 0.0;
+            if (q < nb)
+                for (int c = 0; c <= q; ++c) h += Wl[q * (NB + 1) + c] * gl[j0 + c];
+            const double z = (q < nb) ? tl[j0 + q] - h / dl[q] : 0.0;
+            zq[q] = z;
+            wave_sync();
+            double xv = 0.0;
+            if (q < nb)
+                for (int qq = q; qq < nb; ++qq) xv += Wl[qq * (NB + 1) + q] * zq[qq];
+            wave_sync();
+            if (tid < nb) {
+                tl[j0 + tid] = xv;
+                x[idx[j0 + tid]] = xv;
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < j0; q += nt) {
+            const double* Aq = Fm + (int64_t)q * m + j0;
+            double v = 0.0;
+            if (nb == NB) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) v += Aq[c] * tl[j0 + c];
+            } else {
+                for (int c = 0; c < nb; ++c) v += Aq[c] * tl[j0 + c];
+            }
+            gl[q] += v;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st,
@@ -1127,6 +1672,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     d_y.alloc((size_t)std::max<int64_t>(plan.n, 1));
     d_tbig.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
     d_tsol.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
+    d_dvec.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
     d_status.alloc(1);
     d_status.zero(st);
 
@@ -1142,6 +1688,17 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     else
         (void)hipGetLastError();
 
+    // inverse-based large-front path: needs the > 64 KB dynamic LDS opt-in for its single-workgroup solves
+    bool inv_ok = true;
+    if (const char* e = getenv("MGBHIP_OLD_BIG"); e && e[0] == '1') inv_ok = false;
+    if (inv_ok) {
+        const int lds = (2 * BIG_INV_MAX_M + NB * (NB + 1) + 4 * NB + 8) * (int)sizeof(double);
+        if (hipFuncSetAttribute((const void*)mf_fwd_inv, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mf_bwd_inv, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            inv_ok = false;
+        }
+    }
     static const int32_t classes[] = {16, 32, 48, 64, 88, 128};
     level_launches.clear();
     const int32_t nlev = (int32_t)plan.level_ptr.size() - 1;
@@ -1167,6 +1724,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             L.max_m = plan.fronts[j - 1].m;
             L.max_k = 0;
             L.tiny = (l == 0 && cls == 16);     // leaves with m <= 16: 16 lanes per front
+            L.inv = (cls == 0 && L.max_m <= BIG_INV_MAX_M && inv_ok);
             for (int32_t q = i; q < j; ++q) L.max_k = std::max(L.max_k, plan.fronts[q].k);
             level_launches[l].push_back(L);
             i = j;
@@ -1247,6 +1805,17 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 else
                     hipLaunchKernelGGL(mf_factor_small<32>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
                                        d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+            } else if (L.inv) {
+                const dim3 ga((L.max_m + CT - 1) / CT, L.count);
+                hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,
+                                   d_a_src.p, d_a_dst.p, d_a_colptr.p, d_values, d_arena.p);
+                for (int j0 = 0; j0 < L.max_k; j0 += NB) {
+                    const int rem = L.max_m - j0;
+                    const int T = std::max(0, (rem - 1 + ST - 1) / ST);
+                    const dim3 gs(T * (T + 1) / 2 + 1, L.count);         // trailing tiles + the look-ahead workgroup
+                    hipLaunchKernelGGL(mf_big_step, gs, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p, d_dscr.p,
+                                       d_dvec.p, d_status.p, j0 == 0 ? 1 : 0);
+                }
             } else {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
                 hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,
@@ -1290,6 +1859,10 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
                 hipLaunchKernelGGL(mf_forward_small, dim3((L.count + 3) / 4), dim3(256), (size_t)4 * ts * sizeof(double),
                                    st, d_fronts.p, L.first, L.count, ts, d_front_idx.p, d_children.p, d_rel.p,
                                    d_arena.p, d_b, d_y.p, d_uvec.p);
+            } else if (L.inv) {
+                const size_t lds = (size_t)(((L.max_m + 1) & ~1) + NB * (NB + 1) + 2 * NB) * sizeof(double);
+                hipLaunchKernelGGL(mf_fwd_inv, dim3(L.count), dim3(BIGI_THREADS), lds, st, d_fronts.p, L.first,
+                                   d_front_idx.p, d_children.p, d_rel.p, d_arena.p, d_dvec.p, d_b, d_y.p, d_uvec.p);
             } else if (L.max_m <= BIG1_MAX_M) {
                 const size_t lds = (size_t)(((L.max_m + 1) & ~1) + NB * (NB + 1)) * sizeof(double);
                 hipLaunchKernelGGL(mf_fwd_big1, dim3(L.count), dim3(BIG1_THREADS), lds, st, d_fronts.p, L.first,
@@ -1322,6 +1895,10 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
             } else if (L.cls) {
                 hipLaunchKernelGGL(mf_backward_small, dim3((L.count + 3) / 4), dim3(256), 0, st, d_fronts.p, L.first,
                                    L.count, d_front_idx.p, d_arena.p, d_y.p, d_x);
+            } else if (L.inv) {
+                const size_t lds = (size_t)(((L.max_m + 1) & ~1) + ((L.max_k + 1) & ~1) + NB * (NB + 1) + 2 * NB) * sizeof(double);
+                hipLaunchKernelGGL(mf_bwd_inv, dim3(L.count), dim3(BIGI_THREADS), lds, st, d_fronts.p, L.first,
+                                   d_front_idx.p, d_arena.p, d_dvec.p, d_y.p, d_x);
             } else if (L.max_m <= BIG1_MAX_M) {
                 const size_t lds = (size_t)(((L.max_m + 1) & ~1) + NB * (NB + 1)) * sizeof(double);
                 hipLaunchKernelGGL(mf_bwd_big1, dim3(L.count), dim3(BIG1_THREADS), lds, st, d_fronts.p, L.first,
@@ -1342,6 +1919,10 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
     MGB_HIP_CHECK(hipGetLastError());
     if (timers) timers->end();
 }
+
+#ifdef MGB_STEP_PROBE
+void mf_debug_probe(long long* out64) { (void)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_probe), 64 * sizeof(long long)); }
+#endif
 
 void MfSolver::status_async(int32_t* h_dst, hipStream_t st) const {
     MGB_HIP_CHECK(hipMemcpyAsync(h_dst, d_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -20,6 +20,7 @@ struct MfLaunch {          // one kernel launch: a contiguous range of fronts of
     int32_t cls;           // LDS working size (0 = large-front multi-workgroup path)
     int32_t max_m, max_k;  // largest front / pivot block in the range
     bool tiny = false;     // leaf fronts with m <= 16: 16-lanes-per-front kernels
+    bool inv = false;      // large fronts on the inverse-based path (W_j = L_jj^{-1} in the arena, pivots in dvec)
 };
 
 class MfSolver {
@@ -42,7 +43,7 @@ class MfSolver {
    private:
     DevBuf<FrontDev> d_fronts;
     DevBuf<int32_t> d_front_idx, d_children, d_rel, d_a_src, d_a_dst, d_a_colptr;
-    DevBuf<double> d_arena, d_uvec, d_y, d_tbig, d_tsol, d_dscr;
+    DevBuf<double> d_arena, d_uvec, d_y, d_tbig, d_tsol, d_dscr, d_dvec;
     DevBuf<int32_t> d_status;
     std::vector<std::vector<MfLaunch>> level_launches;   // per level, leaves first (factorization: one per LDS class)
     std::vector<std::vector<MfLaunch>> level_solves;     // triangular solves: all LDS-class fronts of a level in one launch

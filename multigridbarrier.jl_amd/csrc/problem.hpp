@@ -14,6 +14,13 @@ struct mgbhip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     mgbhip::StageTimers timers;
+    mgbhip::DevBuf<double> vscratch, vscal;   // reduction scratch of the device-vector API
+};
+
+struct mgbhip_vec {
+    mgbhip_ctx* ctx = nullptr;
+    mgbhip::DevBuf<double> buf;
+    int64_t len = 0;
 };
 
 namespace mgbhip {

@@ -85,7 +85,12 @@ class Options(C.Structure):
     _fields_ = [("tol", C.c_double), ("t", C.c_double), ("kappa", C.c_double), ("maxit", C.c_int32),
                 ("max_newton", C.c_int32), ("ls_beta", C.c_double), ("ls_c1", C.c_double),
                 ("line_search", C.c_int32), ("stop_lambda_tol", C.c_double), ("stop_theta", C.c_double),
-                ("finalize", C.c_int32), ("finalize_theta", C.c_double), ("early_stop", C.c_int32)]
+                ("finalize", C.c_int32), ("finalize_theta", C.c_double), ("early_stop", C.c_int32),
+                ("stopping_criterion", C.c_void_p), ("early_stop_fn", C.c_void_p), ("user", C.c_void_p)]
+
+
+STOP_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p)
+EARLY_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_double, C.c_void_p)
 
 
 class _CoreResult(C.Structure):
@@ -102,6 +107,10 @@ EXPORTS = [
     "mgbhip_level_size", "mgbhip_f0", "mgbhip_f1", "mgbhip_f2", "mgbhip_hessian_pattern", "mgbhip_solve",
     "mgbhip_node_barrier", "mgbhip_node_slack", "mgbhip_mgb_core", "mgbhip_matched_t",
     "mgbhip_default_options", "mgbhip_stage_ms", "mgbhip_reset_stage_timers", "mgbhip_solver_stats",
+    "mgbhip_vec_alloc", "mgbhip_vec_free", "mgbhip_vec_len", "mgbhip_vec_upload", "mgbhip_vec_download",
+    "mgbhip_vec_fill", "mgbhip_vec_copy", "mgbhip_vec_axpy", "mgbhip_vec_scale", "mgbhip_vec_dot",
+    "mgbhip_vec_norm", "mgbhip_vec_isfinite", "mgbhip_f0_d", "mgbhip_f1_d", "mgbhip_f2_d", "mgbhip_solve_d",
+    "mgbhip_prolong_add",
 ]
 
 
@@ -146,6 +155,25 @@ def load_library():
     lib.mgbhip_stage_ms.argtypes = [C.c_void_p, C.c_char_p, _dp, C.POINTER(C.c_int64)]
     lib.mgbhip_reset_stage_timers.argtypes = [C.c_void_p, C.c_int]
     lib.mgbhip_solver_stats.argtypes = [C.c_void_p, C.c_int32, _dp]
+    vp = C.c_void_p
+    lib.mgbhip_vec_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
+    lib.mgbhip_vec_free.argtypes = [vp]
+    lib.mgbhip_vec_len.argtypes = [vp]
+    lib.mgbhip_vec_len.restype = C.c_int64
+    lib.mgbhip_vec_upload.argtypes = [vp, _dp, C.c_int64]
+    lib.mgbhip_vec_download.argtypes = [vp, _dp, C.c_int64]
+    lib.mgbhip_vec_fill.argtypes = [vp, C.c_double]
+    lib.mgbhip_vec_copy.argtypes = [vp, vp]
+    lib.mgbhip_vec_axpy.argtypes = [C.c_double, vp, vp]
+    lib.mgbhip_vec_scale.argtypes = [C.c_double, vp]
+    lib.mgbhip_vec_dot.argtypes = [vp, vp, _dp]
+    lib.mgbhip_vec_norm.argtypes = [vp, _dp]
+    lib.mgbhip_vec_isfinite.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.mgbhip_f0_d.argtypes = [vp, C.c_int32, vp, vp, vp, _dp]
+    lib.mgbhip_f1_d.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+    lib.mgbhip_f2_d.argtypes = [vp, C.c_int32, vp, vp, vp]
+    lib.mgbhip_solve_d.argtypes = [vp, C.c_int32, vp, vp]
+    lib.mgbhip_prolong_add.argtypes = [vp, C.c_int32, vp, vp]
     _LIB = lib
     return lib
 
@@ -181,6 +209,81 @@ class HipContext:
     def close(self):
         if self.handle:
             self.lib.mgbhip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceVector:
+    """`mgbhip_vec`: a device-resident vector with the algebra the reference's generic `newton`
+    needs from its vector type (`+`, `-`, scalar `*`, `dot`, `norm`, `all(isfinite)`; the CUDA
+    extension gets these from CuArray, ext/MultiGridBarrierCUDAExt/mgb_interface.jl:14-41)."""
+
+    def __init__(self, ctx: "HipContext", data=None, length: Optional[int] = None):
+        self.ctx, self.lib = ctx, ctx.lib
+        if data is not None:
+            data = _f64(np.asarray(data, dtype=np.float64).reshape(-1))
+            length = data.size
+        h = C.c_void_p()
+        _check(self.lib, self.lib.mgbhip_vec_alloc(ctx.handle, int(length), C.byref(h)))
+        self.handle, self.n = h, int(length)
+        if data is not None and length:
+            _check(self.lib, self.lib.mgbhip_vec_upload(h, _ptr(data), length))
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.n)
+        if self.n:
+            _check(self.lib, self.lib.mgbhip_vec_download(self.handle, _ptr(out), self.n))
+        return out
+
+    def copy(self) -> "DeviceVector":
+        out = DeviceVector(self.ctx, length=self.n)
+        _check(self.lib, self.lib.mgbhip_vec_copy(out.handle, self.handle))
+        return out
+
+    def axpy(self, alpha: float, x: "DeviceVector") -> "DeviceVector":
+        _check(self.lib, self.lib.mgbhip_vec_axpy(float(alpha), x.handle, self.handle))
+        return self
+
+    def __add__(self, o):
+        return self.copy().axpy(1.0, o)
+
+    def __sub__(self, o):
+        return self.copy().axpy(-1.0, o)
+
+    def __mul__(self, a):
+        out = self.copy()
+        _check(self.lib, self.lib.mgbhip_vec_scale(float(a), out.handle))
+        return out
+
+    __rmul__ = __mul__
+
+    def fill(self, value: float):
+        _check(self.lib, self.lib.mgbhip_vec_fill(self.handle, float(value)))
+        return self
+
+    def dot(self, o) -> float:
+        out = C.c_double()
+        _check(self.lib, self.lib.mgbhip_vec_dot(self.handle, o.handle, C.cast(C.byref(out), _dp)))
+        return out.value
+
+    def norm(self) -> float:
+        out = C.c_double()
+        _check(self.lib, self.lib.mgbhip_vec_norm(self.handle, C.cast(C.byref(out), _dp)))
+        return out.value
+
+    def all_isfinite(self) -> bool:
+        out = C.c_int32()
+        _check(self.lib, self.lib.mgbhip_vec_isfinite(self.handle, C.byref(out)))
+        return bool(out.value)
+
+    def close(self):
+        if self.handle:
+            self.lib.mgbhip_vec_free(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -316,6 +419,32 @@ class DeviceProblem:
         g = np.empty(self.level_sizes[level])
         _check(self.lib, self.lib.mgbhip_f1(self.handle, level, _ptr(s), _ptr(c), _ptr(z0), _ptr(g)))
         return g
+
+    # -- the same closures on device-resident vectors (nothing but scalars crosses PCIe) --------
+    def vec(self, data=None, length=None) -> DeviceVector:
+        return DeviceVector(self.ctx, data, length)
+
+    def f0_d(self, level: int, s: DeviceVector, c: DeviceVector, z0: DeviceVector) -> float:
+        out = C.c_double()
+        _check(self.lib, self.lib.mgbhip_f0_d(self.handle, level, s.handle, c.handle, z0.handle, C.cast(C.byref(out), _dp)))
+        return out.value
+
+    def f1_d(self, level: int, s: DeviceVector, c: DeviceVector, z0: DeviceVector) -> DeviceVector:
+        g = DeviceVector(self.ctx, length=self.level_sizes[level])
+        _check(self.lib, self.lib.mgbhip_f1_d(self.handle, level, s.handle, c.handle, z0.handle, g.handle))
+        return g
+
+    def f2_d(self, level: int, s: DeviceVector, c: DeviceVector, z0: DeviceVector) -> None:
+        _check(self.lib, self.lib.mgbhip_f2_d(self.handle, level, s.handle, c.handle, z0.handle))
+
+    def solve_d(self, level: int, g: DeviceVector) -> DeviceVector:
+        x = DeviceVector(self.ctx, length=g.n)
+        _check(self.lib, self.lib.mgbhip_solve_d(self.handle, level, g.handle, x.handle))
+        return x
+
+    def prolong_add(self, level: int, s: DeviceVector, z: DeviceVector) -> DeviceVector:
+        _check(self.lib, self.lib.mgbhip_prolong_add(self.handle, level, s.handle, z.handle))
+        return z
 
     def hessian_pattern(self, level: int):
         nnz = C.c_int64()

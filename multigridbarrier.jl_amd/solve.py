@@ -9,6 +9,7 @@ diagnostics the reference returns in `MGBSOL`.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 import time
 from dataclasses import dataclass, field
@@ -68,7 +69,15 @@ def _barrier_weights(w: np.ndarray, barrier_nodes):
     return nz / m
 
 
-def _options(P, tol, t, kappa, maxit, max_newton, line_search, stopping_criterion, finalize, early_stop):
+def _options(P, tol, t, kappa, maxit, max_newton, line_search, stopping_criterion, finalize, early_stop,
+             early_stop_fn=None, keep=None):
+    """Reference keyword arguments -> `mgbhip_options`.  `stopping_criterion` is either a tagged tuple
+    selecting a built-in rule or any callable with the reference's signature
+    `stop(ymin, ynext, gmin, gnext, n, ndecmin, ndec) -> bool` (src/newton.jl:187,222-225): `gnext` arrives
+    as a one-element array holding its norm (so `norm(gnext)` is right) and `n` as None -- the vectors
+    stay on the device; `early_stop_fn` any callable
+    `z -> bool` or `(z, t) -> bool` on the stacked iterate (src/mgb.jl:85-89).  Callables cross the C
+    ABI as function pointers; `keep` collects the ctypes thunks so they outlive the call."""
     o = P.default_options()
     if tol is not None:
         o.tol = float(tol)
@@ -94,7 +103,13 @@ def _options(P, tol, t, kappa, maxit, max_newton, line_search, stopping_criterio
                 o.ls_beta = float(args[0])
         else:
             raise ValueError("line_search must be ('backtracking', beta, c1) or ('illinois', beta)")
-    if stopping_criterion is not None:
+    if callable(stopping_criterion):
+        fn = stopping_criterion
+        thunk = dev.STOP_FN(lambda ymin, ynext, gmin, gn, ndecmin, ndec, _u:
+                            1 if fn(ymin, ynext, gmin, np.array([gn]), None, ndecmin, ndec) else 0)
+        keep.append(thunk)
+        o.stopping_criterion = C.cast(thunk, C.c_void_p)
+    elif stopping_criterion is not None:
         kind = stopping_criterion[0]
         if kind == "inexact":
             o.stop_lambda_tol, o.stop_theta = float(stopping_criterion[1]), float(stopping_criterion[2])
@@ -107,6 +122,17 @@ def _options(P, tol, t, kappa, maxit, max_newton, line_search, stopping_criterio
     elif finalize is not None and finalize is not True:
         o.finalize, o.finalize_theta = 1, float(finalize[1] if isinstance(finalize, (tuple, list)) else finalize)
     o.early_stop = int(early_stop)
+    if early_stop_fn is not None:
+        import inspect
+        two = len(inspect.signature(early_stop_fn).parameters) >= 2
+        zn = P.nu * P.n
+
+        def _early(zp, t, _u):
+            z = np.ctypeslib.as_array(zp, shape=(zn,)).copy()
+            return 1 if (early_stop_fn(z, t) if two else early_stop_fn(z)) else 0
+        thunk = dev.EARLY_FN(_early)
+        keep.append(thunk)
+        o.early_stop_fn = C.cast(thunk, C.c_void_p)
     return o
 
 
@@ -129,9 +155,8 @@ def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[floa
                stopping_criterion=None, line_search=None, finalize=None, barrier_nodes="default",
                printlog=lambda *a: None, early_stop=None):
     """reference: src/mgb.jl:332-584."""
-    if early_stop is not None:
-        raise NotImplementedError("user early_stop callbacks are not supported by the device-resident t-ramp")
     prob = D.prob
+    keep: list = []          # ctypes thunks of user callables: alive until the solves return
     main = D.main
     M1 = prob.M[0]
     if t_feasibility is None:
@@ -165,7 +190,7 @@ def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[floa
             feas.set_box(float(b), Rbox)
             failure = None
             try:
-                opt = _options(feas, t=t_feasibility, early_stop=1, **common)
+                opt = _options(feas, t=t_feasibility, early_stop=1, keep=keep, **common)
                 SOL_feasibility = _run_core(feas, z1, c1, opt, "feasibility phase")
             except (MGBConvergenceFailure, dev.MGBHipError) as e2:   # each round is a probe (src/mgb.jl:505-515)
                 failure = e2
@@ -200,7 +225,7 @@ def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[floa
         printlog("_matched_t: starting main ramp at t=", tm)
         t = min(t, tm)
     main.set_barrier_weights(bw_main)
-    opt = _options(main, t=t, early_stop=0, **common)
+    opt = _options(main, t=t, early_stop=0, early_stop_fn=early_stop, keep=keep, **common)
     SOL_main = _run_core(main, z2, c0, opt, "main phase")
     z = SOL_main["z"].reshape(ncomp, m).T.copy()
     return dict(z=z, SOL_feasibility=SOL_feasibility, SOL_main=SOL_main)

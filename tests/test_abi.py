@@ -26,12 +26,26 @@ def test_exports_every_declared_symbol():
     assert sorted(device.EXPORTS) == declared
 
 
-def test_struct_layouts_match_header_sizes():
+def test_struct_layouts_match_the_compiled_header():
+    """The ctypes mirrors in device.py against the C compiler's own sizeof/offsetof of include/mgbhip.h
+    (printed by the compiled caller tests/csrc/abi_smoke.c --layout): no hand-computed sizes."""
+    import subprocess
+    from test_c_abi import build_c_caller
     lib, device = _lib()
-    # sizes computed from the header's field lists (natural alignment, LP64)
-    assert C.sizeof(device._Piece) == 3 * 4 + 4 * 4 + 4 + 4 * 8 + 2 * 8 + 8       # 28 -> pad to 32, pointers, consts, select
-    assert C.sizeof(device._CSR) == 40
-    assert C.sizeof(device.Options) == 8 * 3 + 4 * 2 + 8 * 2 + 8 + 8 * 2 + 8 + 8 + 8
+    out = subprocess.run([build_c_caller(), "--layout"], capture_output=True, text=True, check=True).stdout
+    mirror = {"mgbhip_piece": device._Piece, "mgbhip_cone": device._Cone, "mgbhip_csr": device._CSR,
+              "mgbhip_problem_desc": device._Desc, "mgbhip_options": device.Options,
+              "mgbhip_core_result": device._CoreResult}
+    seen = 0
+    for ln in out.strip().splitlines():
+        kind, what, val = ln.split()
+        if kind == "sizeof":
+            assert C.sizeof(mirror[what]) == int(val), ln
+        else:
+            st, field = what.split(".")
+            assert getattr(mirror[st], field).offset == int(val), ln
+        seen += 1
+    assert seen >= 35
 
 
 def test_no_gpu_is_an_error_not_a_fallback():

@@ -557,3 +557,33 @@ def test_default_hierarchy_initial_centring_at_L8_is_pinned():
     prob10 = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 8), prolongator=m.amg_ruge_stuben(max_coarse=10)), p=1.5)
     sol = m.mgb_solve(prob10)
     assert np.isfinite(sol.z).all() and int(sol.SOL_main["its"].sum()) < 400
+
+
+def test_user_stopping_criterion_and_early_stop_callables():
+    """`stopping_criterion=` and `early_stop=` accept arbitrary callables like the reference's keyword
+    arguments (src/mgb.jl:85-89, :360): they cross the C ABI as function pointers."""
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 3)), p=1.5)
+    n = prob.M[0].w.size
+    calls = {"stop": 0, "early": 0}
+
+    def my_stop(ymin, ynext, gmin, gnext, nvec, ndecmin, ndec):    # the reference's stopping_inexact, restated by the caller
+        calls["stop"] += 1
+        return (ndec < 0.25 / np.sqrt(n)) or (ynext >= ymin and np.linalg.norm(gnext) >= 0.9 * gmin)
+    base = m.mgb_solve(prob)
+    sol = m.mgb_solve(prob, stopping_criterion=my_stop)
+    assert calls["stop"] > 50 and np.array_equal(sol.z, base.z)
+    assert np.array_equal(sol.SOL_main["its"], base.SOL_main["its"])
+    ref = O.mgb_solve(prob, stopping_criterion=my_stop)
+    assert np.abs(sol.z - ref["z"]).max() < 1e-8
+    # early_stop(z): leave the t-ramp once the slack component drops below 1 everywhere
+    s_of = lambda z: z[n:2 * n]
+
+    def my_early(z):
+        calls["early"] += 1
+        return bool(s_of(z).max() < 8.0)
+    sol_e = m.mgb_solve(prob, early_stop=my_early)
+    ref_e = O.mgb_solve(prob, early_stop=my_early)
+    assert calls["early"] >= 2
+    assert sol_e.SOL_main["ts"][-1] < base.SOL_main["ts"][-1]            # stopped before 1/tol
+    assert np.allclose(sol_e.SOL_main["ts"], ref_e["SOL_main"]["ts"])
+    assert np.abs(sol_e.z - ref_e["z"]).max() < 1e-8 and s_of(stacked(sol_e.z)).max() < 8.0

@@ -1,0 +1,20 @@
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import mgb_amd as m
+from mgb_amd.device import DeviceMGBProblem
+prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 9), prolongator=m.amg_ruge_stuben(max_coarse=300)), p=1.0)
+D = DeviceMGBProblem(prob); P = D.main
+J = len(P.level_sizes) - 1
+z0 = np.ascontiguousarray(prob.g.T).reshape(-1); c = 0.1 * prob.f; s = np.zeros(P.level_sizes[J])
+g = P.f1(J, s, c, z0); P.f2(J, s, c, z0, want_matrix=False)
+for _ in range(3):
+    P.solve(J, g)
+out = (C.c_longlong * 64)()
+P.lib.mgbhip_debug_probe(out)
+v = np.array(out[:])
+print("look-ahead WG (us since entry):", [round((v[i] - v[0]) * 0.01, 2) for i in range(8)])
+print("tile 0 WG     (us since entry):", [round((v[16 + i] - v[16]) * 0.01, 2) for i in range(5)])
+print("tile0 entry - LA entry (us):", (v[16] - v[0]) * 0.01)
+print("LDLT shader cycles:", v[33] - v[32], "-> clock GHz ~", (v[33] - v[32]) / ((v[5] - v[4]) * 10.0))
+D.close()
