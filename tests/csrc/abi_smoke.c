@@ -152,10 +152,15 @@ int main(int argc, char** argv) {
     CHECK(mgbhip_vec_dot(vg, vx, &incd));
     CHECK(mgbhip_vec_norm(vg, &nrm));
     CHECK(mgbhip_vec_isfinite(vx, &fin));
-    /* a damped step s = -0.5 x, then z += R s on the device; the objective must decrease (Armijo) */
-    CHECK(mgbhip_vec_axpy(-0.5, vx, vs));
-    double y1 = 0;
-    CHECK(mgbhip_f0_d(P, J, vs, vc, vz, &y1));
+    /* backtracking line search on the device vectors (src/newton.jl:139-154): s = -sigma x, sigma halved
+     * until the objective is finite and satisfies Armijo; then z += R s on the device */
+    double y1 = 0, sigma = 1.0;
+    for (int it = 0; it < 60; ++it, sigma *= 0.5) {
+        CHECK(mgbhip_vec_fill(vs, 0.0));
+        CHECK(mgbhip_vec_axpy(-sigma, vx, vs));
+        CHECK(mgbhip_f0_d(P, J, vs, vc, vz, &y1));
+        if (isfinite(y1) && y1 <= y0d - 0.1 * sigma * incd) break;
+    }
     CHECK(mgbhip_prolong_add(P, J, vs, vz));
     CHECK(mgbhip_vec_fill(vs, 0.0));
     double y1b = 0;
@@ -163,7 +168,7 @@ int main(int argc, char** argv) {
     double gn = 0;
     for (int64_t i = 0; i < m; ++i) gn += g[i] * g[i];
     printf("newton_step host %.17g %.17g device %.17g %.17g norm %.17g %.17g finite %d armijo %.17g %.17g %.17g\n", y0, inc,
-           y0d, incd, sqrt(gn), nrm, (int)fin, y1, y1b, y0 - 0.1 * 0.5 * inc);
+           y0d, incd, sqrt(gn), nrm, (int)fin, y1, y1b, y0 - 0.1 * sigma * inc);
     mgbhip_vec_free(vs); mgbhip_vec_free(vc); mgbhip_vec_free(vz); mgbhip_vec_free(vg); mgbhip_vec_free(vx);
 
     /* ---- the full solve: mgb_core with the reference defaults ----------------------------------- */
