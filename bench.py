@@ -29,16 +29,24 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-F2_BYTES_PER_NODE = 347.0        # compulsory bytes/node of f2 (fem2d_P2 default problem)
+# SURVEY.md section 8(d), compulsory bytes per broken node of the fem2d_P2 default problem
+BYTES = dict(f0=219.0, f1=231.0, f2=347.0, assemble=488.0)          # total 1285 B / node / Newton iteration
+# bytes the f2 kernel itself moves: z0 + R*s arrives through the cached prolongation
+# kernel and the diagonal ss block is stored compactly -> 128 B in + 120 B out per node
+F2_MOVED_BYTES_PER_NODE = 248.0
 
 
-# Hierarchy variants tried in order.  The reference's default `amg_ruge_stuben(max_coarse=2)`
-# coarsens down to 2-3 unknowns; at L=9 the Newton solves in those tiny coarse spaces creep
-# along the barrier wall during the initial centring (the regime the reference's comments at
-# src/mgb.jl:64-71 describe) and the t-ramp reports :stall, so the workload keeps the coarsest
-# space at a few hundred unknowns (`max_coarse` is a documented knob of the reference's
-# prolongator factory, src/multigrid.jl:304-306).  DESIGN.md section "Workload" has the details.
-HIERARCHIES = [dict(max_coarse=300), dict(max_levels=6), dict(theta=0.5), dict()]
+# Hierarchy policy.  The workload runs the reference default `amg(geom)` = amg_ruge_stuben(max_coarse=2)
+# (src/multigrid.jl:296).  With this package's restatement of AlgebraicMultigrid.jl's Ruge-Stueben that
+# ladder converges for p = 1.0 at L = 9; for p = 1.5 the initial centring stalls in the 2-4-unknown
+# coarse spaces at L >= 8 (device and oracle agree, tests/test_gpu_parity.py::
+# test_default_hierarchy_initial_centring_at_L8_is_pinned), so the p = 1.5 line uses
+# the smallest deviation that converges, max_coarse=10 -- a documented knob of the reference's factory
+# (src/multigrid.jl:304-306) -- and says so in its `hierarchy` field.
+def hierarchies(p, L):
+    if p >= 1.25 and L >= 8:
+        return [dict(max_coarse=10), dict(max_coarse=50), dict(max_coarse=300)]
+    return [dict(), dict(max_coarse=10), dict(max_coarse=300)]
 
 
 def build_problem(L, p, rs_kwargs):
@@ -64,28 +72,108 @@ def cpu_baseline(prob, budget_s):
         done = False
     el = time.perf_counter() - t0
     its = st.get("newton_its", 0)
+    import shutil
     return dict(value=its / el if el > 0 else 0.0, unit="newton_iters/s", cores=1, kind="port",
+                host_cores=os.cpu_count(),
+                all_cores_note=("the port's evaluate/assemble (NumPy/SciPy sparse) and its host multifrontal Cholesky are "
+                                "single-threaded like the reference's Julia path (bench.md:81); no all-cores figure exists for it"),
+                julia=(shutil.which("julia") or "unavailable: reference Julia path cannot be timed on this box"),
                 sample=(f"{its} Newton iterations of the same workload from the default start "
                         f"({'complete solve' if done else f'stopped at the {budget_s:.0f} s budget'}); NumPy/SciPy "
                         "evaluate+assemble, single-thread host multifrontal Cholesky (oracle/csrc/mf_host.cpp)"),
                 seconds=el, solve_seconds=st.get("solve_s", 0.0))
 
 
+def measure_traffic(L, p, rs_kwargs):
+    """HBM bytes of one fine-level f2 launch from rocprofv3 PMC counters, measured live: two child
+    processes (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md), started before this
+    process touches the GPU, each running tools/gpu_kernels.py (3 evaluations of f0/f1/f2 + assembly at the
+    fine level of the same workload).  FETCH_SIZE is doubled for wide coalesced reads on gfx950 and both
+    counters are in KiB, as that guide prescribes.  Returns (bytes or None, note)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mgb_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.join(HERE, "tools", "gpu_kernels.py"), str(L), str(p), "3", json.dumps(rs_kwargs)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+            tot, cnt = 0.0, 0
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == counter and "elem_f2_fast" in r["Kernel_Name"]:
+                    tot += float(r["Counter_Value"]); cnt += 1
+            if cnt == 0:
+                return None, f"no elem_f2_fast rows in the {counter} pass"
+            vals[counter] = tot / cnt
+        except Exception as e:      # profiler unavailable / refused: report, never guess
+            return None, f"{counter} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 1024.0 * (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (KiB; FETCH doubled on gfx950)"
+
+
+def run_workload(m, DeviceMGBProblem, mgb_driver, MGBConvergenceFailure, L, p, dev_index, warmup, rank):
+    """Build the problem on the first hierarchy variant that converges; returns everything the timed loop needs."""
+    for rs_kwargs in hierarchies(p, L):
+        t0 = time.perf_counter()
+        prob = build_problem(L, p, rs_kwargs)
+        t_setup = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        D = DeviceMGBProblem(prob, device_id=dev_index)
+        t_upload = time.perf_counter() - t0
+        try:
+            t0 = time.perf_counter()
+            mgb_driver(D)          # untimed: builds plans + symbolic factorizations, proves convergence
+            t_first = time.perf_counter() - t0
+            for _ in range(max(warmup - 1, 0)):
+                mgb_driver(D)
+            return prob, D, rs_kwargs, dict(host_setup=t_setup, upload=t_upload, first_solve=t_first)
+        except MGBConvergenceFailure as e:
+            if rank == 0:
+                print(f"bench: hierarchy {rs_kwargs} failed ({e.code}); trying the next variant", file=sys.stderr)
+            D.close()
+    raise SystemExit("bench.py: no hierarchy variant converged")
+
+
+def timed_solves(mgb_driver, D, steps):
+    its_total, solve_s, core_s, last = 0, 0.0, 0.0, None
+    for _ in range(steps):
+        SOL = mgb_driver(D)
+        last = SOL
+        for key in ("SOL_feasibility", "SOL_main"):
+            if SOL[key] is not None:
+                its_total += int(SOL[key]["its"].sum())
+                solve_s += SOL[key]["solve_seconds"]
+                core_s += SOL[key]["t_elapsed"]
+    return its_total, solve_s, core_s, last
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--L", type=int, default=int(os.environ.get("MGB_BENCH_L", "9")))
     ap.add_argument("--p", type=float, default=float(os.environ.get("MGB_BENCH_P", "1.0")))
-    ap.add_argument("--cpu-budget", type=float, default=float(os.environ.get("MGB_BENCH_CPU_BUDGET", "25")))
+    ap.add_argument("--cpu-budget", type=float, default=float(os.environ.get("MGB_BENCH_CPU_BUDGET", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes")
+    ap.add_argument("--no-p15", action="store_true", help="skip the north_star p=1.5 line")
     args = ap.parse_args()
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # PMC passes first: child processes, before this process initialises the GPU (rank 0, N = 1 only)
+    traffic, traffic_note = None, "not measured"
+    if world == 1 and rank == 0 and not args.no_traffic and os.environ.get("MGB_BENCH_TRAFFIC", "1") == "1":
+        traffic, traffic_note = measure_traffic(args.L, args.p, hierarchies(args.p, args.L)[0])
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # MGB_BENCH_REHEARSAL=1 (development only): all ranks share GPU 0 and talk over gloo, so that the
@@ -108,44 +196,13 @@ def main():
 
     import mgb_amd as m
     from mgb_amd.device import DeviceMGBProblem
-    from mgb_amd.solve import mgb_driver
+    from mgb_amd.solve import mgb_driver, MGBConvergenceFailure
 
-    from mgb_amd.solve import MGBConvergenceFailure
-    prob = D = None
-    used = None
-    for rs_kwargs in (HIERARCHIES if args.L >= 9 else [dict()] + HIERARCHIES):
-        t0 = time.perf_counter()
-        prob = build_problem(args.L, args.p, rs_kwargs)
-        t_setup = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        D = DeviceMGBProblem(prob, device_id=dev_index)
-        t_upload = time.perf_counter() - t0
-        try:
-            for _ in range(max(args.warmup, 1) if used is None else args.warmup):
-                mgb_driver(D)          # untimed: builds plans + symbolic factorizations, proves convergence
-            used = rs_kwargs
-            break
-        except MGBConvergenceFailure as e:
-            if rank == 0:
-                print(f"bench: hierarchy {rs_kwargs} failed ({e.code}); trying the next variant", file=sys.stderr)
-            D.close()
-            D = None
-    if D is None:
-        raise SystemExit("bench.py: no hierarchy variant converged")
+    prob, D, used, setup = run_workload(m, DeviceMGBProblem, mgb_driver, MGBConvergenceFailure, args.L, args.p, dev_index,
+                                        args.warmup, rank)
     barrier()
     t0 = time.perf_counter()
-    its_total = 0
-    solve_s = 0.0
-    core_s = 0.0
-    last = None
-    for _ in range(args.steps):
-        SOL = mgb_driver(D)
-        last = SOL
-        for key in ("SOL_feasibility", "SOL_main"):
-            if SOL[key] is not None:
-                its_total += int(SOL[key]["its"].sum())
-                solve_s += SOL[key]["solve_seconds"]
-                core_s += SOL[key]["t_elapsed"]
+    its_total, solve_s, core_s, last = timed_solves(mgb_driver, D, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     from mgb_amd.replicas import aggregate
@@ -154,42 +211,38 @@ def main():
     # ---- roofline of the dominant HBM kernel: fused element Hessian (f2), fine level ----
     # One more solve of the same workload, outside the timed region, with the library's hipEvent
     # stage timers switched on (events recorded on the library's own stream around every stage):
-    # the fine-level f2 launches are timed exactly as they occur in the Newton loop.
+    # the fine-level launches are timed exactly as they occur in the Newton loop.
     main = D.main
     fine = len(main.level_sizes) - 1
     n = prob.M[0].w.size
     main.reset_stage_timers(True)
     mgb_driver(D)
-    f2_ms, f2_n = main.stage_ms("f2")
-    asm_ms, asm_n = main.stage_ms("assemble")
-    f0_ms, f0_n = main.stage_ms("f0")
-    f1_ms, f1_n = main.stage_ms("f1")
-    fac_ms, fac_n = main.stage_ms("factor")
-    tri_ms, tri_n = main.stage_ms("trisolve")
+    st = {k: main.stage_ms(k) for k in ("f2", "assemble", "f0", "f1", "restrict", "prolong", "factor", "trisolve")}
     main.reset_stage_timers(False)
-    f2_avg_s = (f2_ms / max(f2_n, 1)) * 1e-3
-    bytes_per_launch = F2_BYTES_PER_NODE * n
-    achieved = bytes_per_launch / f2_avg_s / 1e9 if f2_avg_s > 0 else 0.0
-    # HBM traffic of the same launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
-    # WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced
-    # streams on gfx950; counters are in KiB).  Only valid for the workload it was collected on.
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(HERE, "profiles", "r01_pmc_traffic_L9.json")))
-        if args.L == 9 and n == 917504:
-            traffic = 1024.0 * (2.0 * pmc["elem_f2_fast"]["FETCH_SIZE"] + pmc["elem_f2_fast"]["WRITE_SIZE"])
-    except Exception:
-        traffic = None
-    def _frac(bytes_per_node, ms, cnt):
-        return (bytes_per_node * n / max(ms / max(cnt, 1) * 1e-3, 1e-12) / 1e9) / HBM_PEAK_GBS
-    roofline = dict(bound="hbm", kernel="elem_f2_fast<4,7,SigDefault>: fused Dz + cone Hessian + element blocks, fine level "
-                                        "(the f2 stage of the Newton loop; z0 + R*s is cached from the preceding f1)",
-                    achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, bytes_per_launch=bytes_per_launch, avg_launch_us=f2_avg_s * 1e6, launches=int(f2_n),
-                    assemble_avg_us=(asm_ms / max(asm_n, 1)) * 1e3, assemble_frac=_frac(488.0, asm_ms, asm_n),
-                    f0_avg_us=(f0_ms / max(f0_n, 1)) * 1e3, f0_frac=_frac(219.0, f0_ms, f0_n),
-                    f1_avg_us=(f1_ms / max(f1_n, 1)) * 1e3, f1_frac=_frac(231.0 - 11.4, f1_ms, f1_n),
-                    factor_avg_us=(fac_ms / max(fac_n, 1)) * 1e3, trisolve_avg_us=(tri_ms / max(tri_n, 1)) * 1e3)
+    avg_us = {k: (1e3 * ms / cnt if cnt else 0.0) for k, (ms, cnt) in st.items()}
+    f2_avg_s = avg_us["f2"] * 1e-6
+    gbs = lambda nbytes, us: (nbytes / (us * 1e-6) / 1e9) if us > 0 else 0.0
+    achieved = gbs(BYTES["f2"] * n, avg_us["f2"])
+    # aggregate of SURVEY 8(d): one fine Newton iteration = f2 + assembly + f0 + f1 (prolongation and the
+    # R' gather are part of those stages' stage timers) against 1285 B / node
+    agg_us = avg_us["f2"] + avg_us["assemble"] + avg_us["f0"] + avg_us["f1"] + avg_us["restrict"]
+    roofline = dict(
+        bound="hbm",
+        kernel="elem_f2_fast<4,7,SigDefault>: fused Dz + cone Hessian + element blocks, fine level (the f2 stage of the "
+               "Newton loop; z0 + R*s is cached from the preceding f1)",
+        achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+        numerator="SURVEY 8(d) algorithmic bytes: 347 B/node x n",
+        traffic=traffic, traffic_source=traffic_note,
+        bytes_per_launch=BYTES["f2"] * n, avg_launch_us=avg_us["f2"], launches=int(st["f2"][1]),
+        moved_bytes_model=F2_MOVED_BYTES_PER_NODE * n,
+        moved_gbs=gbs(F2_MOVED_BYTES_PER_NODE * n, avg_us["f2"]),
+        moved_frac=gbs(F2_MOVED_BYTES_PER_NODE * n, avg_us["f2"]) / HBM_PEAK_GBS,
+        measured_gbs=(gbs(traffic, avg_us["f2"]) if traffic else None),
+        measured_frac=(gbs(traffic, avg_us["f2"]) / HBM_PEAK_GBS if traffic else None),
+        aggregate=dict(stages_us={k: avg_us[k] for k in ("f0", "f1", "restrict", "f2", "assemble")}, total_us=agg_us,
+                       bytes=sum(BYTES.values()) * n, gbs=gbs(sum(BYTES.values()) * n, agg_us),
+                       frac=gbs(sum(BYTES.values()) * n, agg_us) / HBM_PEAK_GBS),
+        factor_avg_us=avg_us["factor"], trisolve_avg_us=avg_us["trisolve"])
     stats = main.solver_stats(fine)
 
     out = None
@@ -209,23 +262,42 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"fem2d_P2() p={args.p} L={args.L} default f,g (BASELINE.json configs[2] family), "
-                                   f"AMG hierarchy, n={n} broken nodes, {main.level_sizes[fine]} fine unknowns",
-                       "hierarchy": f"amg_ruge_stuben({used})",
+                                   f"amg(subdivide(fem2d_P2(), {args.L})), n={n} broken nodes, {main.level_sizes[fine]} fine unknowns",
+                       "hierarchy": f"amg_ruge_stuben({used if used else 'max_coarse=2: the reference default'})",
+                       "hierarchy_is_reference_default": not used,
+                       "levels": [int(v) for v in main.level_sizes],
                        "parallelism": "replicas" if world > 1 else "single",
                        "solver_controls": "reference defaults (tol=sqrt(eps), t=0.1, kappa=10, max_newton=8, backtracking)"},
             "wall_clock_to_converge_s": elapsed_max / max(args.steps, 1),
             "newton_iterations_per_solve": its_total / max(args.steps, 1),
             "linear_solve_fraction": solve_s / core_s if core_s > 0 else None,
             "t_steps": int(sm["k"]),
-            "setup_s": {"host_setup": t_setup, "upload": t_upload},
+            "setup_s": setup,
             "factorization": {k: stats[k] for k in ("fronts", "max_front", "factor_flops", "tree_levels", "nnz", "unknowns")},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_budget)
-            if out["cpu_baseline"]["value"] > 0:
-                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     D.close()
+    # ---- north_star target line: fem2d_P2 p = 1.5 at the same L (BASELINE.json north_star), rank 0 / N = 1 ----
+    if rank == 0 and world == 1 and not args.no_p15 and args.p != 1.5:
+        prob15, D15, used15, setup15 = run_workload(m, DeviceMGBProblem, mgb_driver, MGBConvergenceFailure, args.L, 1.5,
+                                                    dev_index, 1, rank)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        its15, ss15, cs15, _ = timed_solves(mgb_driver, D15, args.steps)
+        torch.cuda.synchronize()
+        el15 = time.perf_counter() - t0
+        out["north_star_p15"] = dict(workload=f"fem2d_P2() p=1.5 L={args.L}", value=its15 / el15, unit="newton_iters/s",
+                                     wall_clock_to_converge_s=el15 / max(args.steps, 1),
+                                     newton_iterations_per_solve=its15 / max(args.steps, 1),
+                                     hierarchy=f"amg_ruge_stuben({used15 if used15 else 'max_coarse=2: the reference default'})",
+                                     hierarchy_is_reference_default=not used15,
+                                     levels=[int(v) for v in D15.main.level_sizes],
+                                     linear_solve_fraction=ss15 / cs15 if cs15 > 0 else None, setup_s=setup15)
+        D15.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(prob, args.cpu_budget)
+        if out["cpu_baseline"]["value"] > 0:
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -130,6 +130,9 @@ __device__ __forceinline__ bool wave_ldlt_pipe(double (&a)[NBT], int nb, int lan
     return bad;
 }
 
+#ifdef MGB_STEP_PROBE
+__device__ long long g_probe[64];
+#endif
 // LDL' of a 32 x 32 block by one wave with the multiplier columns broadcast through LDS instead of
 // v_readlane (a readlane + dependent FMA pair costs ~35 cycles on gfx950; a broadcast ds_read_b128
 // delivers two multipliers per issue slot).  Lane r (and its twin r + 32) holds row r in registers.
@@ -143,7 +146,6 @@ __device__ __forceinline__ bool wave_ldlt_lds32(double (&a)[NB], int nb, int lan
     double d = readlane_f64(a[0], 0);
     if (d == 0.0 || !isfinite(d)) bad = true;
     double inv = fast_recip(d);
-    wave_sync();
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         if (j < nb) {
@@ -153,7 +155,7 @@ __device__ __forceinline__ bool wave_ldlt_lds32(double (&a)[NB], int nb, int lan
             const double lr = aj * inv;
             double inv_next = 1.0;
             if (j + 1 < NB) {
-                a[j + 1] -= lr * cb[j + 1];
+                a[j + 1] -= lr * readlane_f64(aj, j + 1);      // the one multiplier on the pivot chain: no LDS round trip
                 if (lane < 32) cn[r] = a[j + 1];
                 if (j + 1 < nb) {
                     const double dn = readlane_f64(a[j + 1], j + 1);
@@ -165,7 +167,8 @@ __device__ __forceinline__ bool wave_ldlt_lds32(double (&a)[NB], int nb, int lan
             for (int c = j + 2; c < NB; ++c) a[c] -= lr * cb[c];
             if (r > j) a[j] = lr;
             inv = inv_next;
-            wave_sync();
+            // no wait here: the LDS unit executes one wave's operations in order, so the reads of the
+            // next column queue behind the write above while the reciprocal chain runs
         }
     }
     return bad;
@@ -1290,7 +1293,6 @@ __device__ __forceinline__ void slice_transform(double (*P)[ST + 1], double (*Po
 }
 
 #ifdef MGB_STEP_PROBE
-__device__ long long g_probe[64];
 #define PROBE(i) do { if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[i] = wall_clock64(); if (!is_la && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[16 + i] = wall_clock64(); } while (0)
 #else
 #define PROBE(i) do { } while (0)

@@ -5,7 +5,8 @@ import numpy as np
 import mgb_amd as m
 from mgb_amd.device import DeviceMGBProblem
 L = int(sys.argv[1]); p = float(sys.argv[2]); reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), L), prolongator=m.amg_ruge_stuben(max_coarse=300)), p=p)
+kw = json.loads(sys.argv[4]) if len(sys.argv) > 4 else {"max_coarse": 300}
+prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), L), prolongator=m.amg_ruge_stuben(**kw)), p=p)
 D = DeviceMGBProblem(prob); P = D.main
 n = prob.M[0].w.size; J = len(P.level_sizes) - 1
 z0 = np.ascontiguousarray(prob.g.T).reshape(-1); c = 0.1 * prob.f; s = np.zeros(P.level_sizes[J])
