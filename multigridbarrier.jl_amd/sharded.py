@@ -1,0 +1,245 @@
+"""Element-sharded evaluate / assemble across ranks.
+
+The broken basis duplicates shared nodes per element, so the operator blocks, weights, cone grids,
+cost grid and the iterate `z0` are element-local: a rank that owns a contiguous element range
+`[e0, e1)` (spatially compact, because `subdivide` keeps the children of a coarse element contiguous,
+reference: src/fem2d_P2.jl:181-204, src/TensorFEM.jl:905-910) needs no halo on the input side.  The
+only coupling is through `R`:
+
+  * the level-J coefficients `s` are replicated (10 MB at L = 9),
+  * `f0`      = sum over ranks of the local partial sums              -> one scalar all-reduce,
+  * `f1`      = sum over ranks of  R_loc' * (local element gradient)   -> only the entries of DoFs whose
+                support crosses a rank boundary (the interface) differ from zero on more than one rank,
+  * `R' H R`  = sum over ranks of  R_loc' * H_blk,loc * R_loc          -> likewise only interface rows.
+
+`ShardedBarrier` evaluates the three closures of the reference's `Barrier` (src/convex.jl:155-202) that
+way: every rank runs the ordinary single-GPU code on its slice of the problem (a `DeviceProblem` built
+from `slice_problem`, or any object with the same f0/f1/f2 methods), then interface entries are summed
+with ONE `all_reduce` on a compact buffer; the batched scalar all-reduce of a Newton iteration
+(f0, <g, n>, |g|^2, finite flag) rides in the same call when the caller passes `extra`.
+
+The 1/n of the flat barrier average is global, so the local problems carry
+`barrier_weights = 1/n_global` (the masked-barrier path, src/convex.jl:213-257) -- no kernel changes.
+
+What does NOT shard is the reference's direct solve: the factorization needs the whole `H`
+(`gather_hessian`).  DESIGN.md section 7 has the traffic numbers and the subtree-to-rank design
+that would shard it.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+from typing import Any, List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+from .blockmatrices import BlockDiag, block_column
+from .convex import Convex, Piece
+from .multigrid import AMG, Geometry
+from .problem import MGBProblem
+
+
+def element_partition(N: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous element ranges, sizes differing by at most one."""
+    base, rem = divmod(int(N), int(world))
+    out, e = [], 0
+    for r in range(world):
+        cnt = base + (1 if r < rem else 0)
+        out.append((e, e + cnt))
+        e += cnt
+    return out
+
+
+def _rows_of(nodes: np.ndarray, n: int, nu: int) -> np.ndarray:
+    return np.concatenate([a * n + nodes for a in range(nu)])
+
+
+def slice_amg(M: AMG, e0: int, e1: int) -> AMG:
+    """The AMG restricted to elements [e0, e1): operator blocks, weights, coordinates and the ROWS of
+    every prolongation; the column spaces (level-J coefficients) stay global."""
+    geom = M.geometry
+    first = M.D_fine[0]
+    p, N = first.active_block.p, first.active_block.N
+    n, nu = p * N, first.nu
+    nodes = np.arange(p * e0, p * e1)
+    ops = {k: BlockDiag(v.data[:, :, e0:e1]) for k, v in geom.operators.items()}
+    g2 = Geometry(discretization=geom.discretization, t=geom.t[:, e0:e1], x=geom.x[:, e0:e1], w=geom.w[nodes], operators=ops)
+    rows = _rows_of(nodes, n, nu)
+    R_loc = [sp.csr_matrix(sp.csr_matrix(R)[rows]) for R in M.R_fine]
+    D_loc = [block_column(ops[name], state, nu) for (state, name) in M.D_spec]
+    return AMG(geometry=g2, x=M.x[nodes], w=M.w[nodes], R_fine=R_loc, D_fine=D_loc, state_names=M.state_names, D_spec=M.D_spec)
+
+
+def slice_convex(Q: Convex, nodes: np.ndarray) -> Convex:
+    pieces = [Piece(pc.kind, pc.idx, pc.A[nodes], pc.b[nodes], None if pc.p is None else pc.p[nodes],
+                    None if pc.mu is None else pc.mu[nodes], pc.colon) for pc in Q.pieces]
+    return Convex(pieces, None if Q.select is None else Q.select[nodes])
+
+
+def slice_problem(prob: MGBProblem, e0: int, e1: int) -> MGBProblem:
+    p = prob.M[0].D_fine[0].active_block.p
+    nodes = np.arange(p * e0, p * e1)
+    M = tuple(slice_amg(Mk, e0, e1) for Mk in prob.M)
+    return MGBProblem(M, prob.f[nodes], prob.g[nodes], slice_convex(prob.Q, nodes), M[0].geometry)
+
+
+@dataclass
+class _LevelPlan:
+    m: int
+    iface: np.ndarray                 # DoFs whose support meets more than one rank (sorted)
+    rowptr: np.ndarray                # global CSR pattern of R'HR (union of the ranks' patterns)
+    colidx: np.ndarray
+    loc2glob: np.ndarray              # position of every local structural nonzero in the global pattern
+    shared: np.ndarray                # global nnz positions touched by more than one rank (sorted)
+    shared_of_local: np.ndarray       # for local nnz in `shared`: (local position, slot in the shared buffer)
+
+
+class ShardedBarrier:
+    """The Barrier closures on an element-sharded problem.
+
+    `local` is this rank's evaluator on its slice: f0(level, s, c_loc, z0_loc) -> float,
+    f1(...) -> (m_J,) array, f2(...) -> scipy CSR (m_J x m_J) holding R_loc' H_loc R_loc.
+    `dist` is `torch.distributed` (initialised) or None for a single rank; `device` the torch device
+    of the reduction buffers ("cpu" with gloo, "cuda" with RCCL)."""
+
+    def __init__(self, prob: MGBProblem, rank: int, world: int, local, dist=None, device: str = "cpu", which: int = 0):
+        self.rank, self.world, self.dist, self.device = rank, world, dist, device
+        M = prob.M[which]
+        first = M.D_fine[0]
+        self.p, self.N, self.nu = first.active_block.p, first.active_block.N, first.nu
+        self.n = self.p * self.N
+        self.parts = element_partition(self.N, world)
+        self.e0, self.e1 = self.parts[rank]
+        self.nodes = np.arange(self.p * self.e0, self.p * self.e1)
+        self.local = local
+        self.M = M
+        self._plans: dict = {}
+        self.bytes_reduced = 0          # payload of the data-path collectives so far (diagnostics)
+
+    # ---- slices of the per-node inputs ------------------------------------------------------------
+    def c_local(self, c: np.ndarray) -> np.ndarray:
+        return np.asarray(c)[self.nodes]
+
+    def z_local(self, z0: np.ndarray) -> np.ndarray:
+        return np.asarray(z0)[_rows_of(self.nodes, self.n, self.nu)]
+
+    # ---- collectives ---------------------------------------------------------------------------------
+    def _allreduce(self, buf: np.ndarray) -> np.ndarray:
+        if self.dist is None or self.world == 1:
+            return buf
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.float64)).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.bytes_reduced += t.numel() * 8
+        return t.cpu().numpy()
+
+    def _gather_objects(self, obj):
+        if self.dist is None or self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    # ---- one-time plans per level (pattern algebra only, no values) -----------------------------
+    def plan(self, level: int, H_loc: Optional[sp.csr_matrix] = None) -> _LevelPlan:
+        if level in self._plans and (H_loc is None or self._plans[level].rowptr is not None):
+            return self._plans[level]
+        R = sp.csr_matrix(self.M.R_fine[level])
+        m = R.shape[1]
+        # interface DoFs: columns of R with rows in more than one rank's node range
+        rows, cols = R.nonzero()
+        owner = np.searchsorted(np.array([self.p * e1 for (_, e1) in self.parts]), rows % self.n, side="right")
+        touch = sp.csr_matrix((np.ones(rows.size), (cols, owner)), shape=(m, self.world))
+        iface = np.flatnonzero(touch.getnnz(axis=1) > 1)
+        pl = _LevelPlan(m=m, iface=iface, rowptr=None, colidx=None, loc2glob=None, shared=None, shared_of_local=None)
+        if H_loc is not None:
+            H_loc = sp.csr_matrix(H_loc)
+            H_loc.sort_indices()
+            key_loc = H_loc.indptr, H_loc.indices
+            keys = np.repeat(np.arange(m, dtype=np.int64), np.diff(H_loc.indptr)) * m + H_loc.indices
+            all_keys = self._gather_objects(keys)
+            uni, counts = np.unique(np.concatenate(all_keys), return_counts=True)
+            pl.rowptr = np.concatenate([[0], np.cumsum(np.bincount(uni // m, minlength=m))]).astype(np.int64)
+            pl.colidx = (uni % m).astype(np.int64)
+            pl.loc2glob = np.searchsorted(uni, keys)
+            pl.shared = np.flatnonzero(counts > 1)
+            slot = np.searchsorted(pl.shared, pl.loc2glob)
+            hit = (slot < pl.shared.size) & (pl.shared[np.minimum(slot, pl.shared.size - 1)] == pl.loc2glob) if pl.shared.size else np.zeros(keys.size, bool)
+            pl.shared_of_local = np.stack([np.flatnonzero(hit), slot[hit]], axis=0)
+        self._plans[level] = pl
+        return pl
+
+    # ---- the closures -------------------------------------------------------------------------------
+    def f0(self, level: int, s, c, z0, extra: Sequence[float] = ()) -> Any:
+        """Global objective; `extra` scalars are summed over ranks in the same all-reduce."""
+        y = self.local.f0(level, s, self.c_local(c), self.z_local(z0))
+        out = self._allreduce(np.array([y, *extra], dtype=np.float64))
+        return float(out[0]) if not extra else (float(out[0]), out[1:])
+
+    def f1(self, level: int, s, c, z0) -> np.ndarray:
+        """Global gradient: interior entries are already complete on their owner and zero elsewhere, so only
+        the interface entries travel; every rank returns the full vector (s is replicated)."""
+        g = np.asarray(self.local.f1(level, s, self.c_local(c), self.z_local(z0)), dtype=np.float64)
+        pl = self.plan(level)
+        if self.world == 1:
+            return g
+        # interface entries: summed; interior entries: exactly one rank holds a non-zero -> the same sum,
+        # sent as one buffer [interface | interior] so that every rank ends with the replicated gradient
+        return self._allreduce(g)
+
+    def f1_interface_only(self, level: int, s, c, z0) -> Tuple[np.ndarray, np.ndarray]:
+        """(local gradient with interface entries summed, interface index list): the distributed form in
+        which a sharded solver would consume it -- payload = |interface| doubles."""
+        g = np.asarray(self.local.f1(level, s, self.c_local(c), self.z_local(z0)), dtype=np.float64).copy()
+        pl = self.plan(level)
+        g[pl.iface] = self._allreduce(g[pl.iface])
+        return g, pl.iface
+
+    def f2(self, level: int, s, c, z0) -> Tuple[np.ndarray, _LevelPlan]:
+        """Values of this rank's part of R'HR on the GLOBAL pattern, with the entries that several ranks
+        contribute to (interface rows) already summed -- payload = |shared| doubles.  Entries no other
+        rank touches stay where they were computed; `gather_hessian` replicates them when a direct solve
+        needs the whole matrix."""
+        H_loc = sp.csr_matrix(self.local.f2(level, s, self.c_local(c), self.z_local(z0)))
+        H_loc.sort_indices()
+        pl = self.plan(level, H_loc)
+        vals = np.zeros(pl.colidx.size)
+        vals[pl.loc2glob] = H_loc.data
+        if self.world > 1 and pl.shared.size:
+            buf = np.zeros(pl.shared.size)
+            buf[pl.shared_of_local[1]] = H_loc.data[pl.shared_of_local[0]]
+            vals[pl.shared] = self._allreduce(buf)
+        return vals, pl
+
+    def gather_hessian(self, vals: np.ndarray, pl: _LevelPlan) -> sp.csr_matrix:
+        """Replicate the whole matrix (what the reference's direct solve needs): shared entries are final
+        on every rank already; the others are non-zero on exactly one rank, so a sum over ranks of the
+        non-shared part is a gather."""
+        if self.world > 1:
+            own = vals.copy()
+            own[pl.shared] = 0.0
+            tot = self._allreduce(own)
+            tot[pl.shared] = vals[pl.shared]
+            vals = tot
+        return sp.csr_matrix((vals, pl.colidx, pl.rowptr), shape=(pl.m, pl.m))
+
+
+class DeviceLocalEvaluator:
+    """This rank's slice on its GPU: an ordinary `DeviceProblem` whose flat barrier average uses the
+    GLOBAL node count (barrier_weights = 1/n_global, or the slice of the caller's weights)."""
+
+    def __init__(self, prob: MGBProblem, rank: int, world: int, device_id: int = 0, barrier_weights=None, which: int = 0):
+        from .device import DeviceProblem, HipContext
+        first = prob.M[which].D_fine[0]
+        N, p = first.active_block.N, first.active_block.p
+        e0, e1 = element_partition(N, world)[rank]
+        nodes = np.arange(p * e0, p * e1)
+        sub = slice_problem(prob, e0, e1)
+        bw = np.full(nodes.size, 1.0 / (p * N)) if barrier_weights is None else np.asarray(barrier_weights)[nodes]
+        self.ctx = HipContext(device_id)
+        self.P = DeviceProblem(self.ctx, sub.M[which], sub.Q, barrier_weights=bw)
+        self.f0, self.f1, self.f2 = self.P.f0, self.P.f1, self.P.f2
+
+    def close(self):
+        self.P.close()
+        self.ctx.close()
