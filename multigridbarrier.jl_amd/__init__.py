@@ -16,7 +16,7 @@ from .spectral import spectral1d, spectral2d, SPECTRAL1D, SPECTRAL2D
 from .amg_prolongators import amg_ruge_stuben, amg_smoothed_aggregation
 from .convex import Convex, Piece, convex_Euclidian_power, convex_linear, convex_piecewise, intersect
 from .parabolic import parabolic_solve, ParabolicSOL
-from .problem import (MGBProblem, assemble, amg, subdivide, find_boundary, default_f, default_g,
+from .problem import (MGBProblem, assemble, amg, subdivide, geometric_mg, find_boundary, default_f, default_g,
                       default_D, default_idx)
 
 try:  # the device layer needs the built shared library; importing the setup layer does not

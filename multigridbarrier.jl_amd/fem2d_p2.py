@@ -393,3 +393,89 @@ def amg(geom: Geometry, prolongator=None, dirichlet_nodes: Dict[str, List[Tuple[
     return assemble_amg_dicts(geom, n_doubled, dirichlet_nodes, refine_full, sizes_full, L_full,
                               K_amg_full, build_dirichlet,
                               full_riders={"broken_P1": _broken_p1_embedding(N, V)})
+
+
+# ---------------------------------------------------------------------------
+# geometric_mg (reference: src/fem2d_P2.jl:468-596)
+# ---------------------------------------------------------------------------
+
+# The reference's 28 x 7 child-interpolation table `reference_triangle(...).refine` x 648
+# (src/fem2d_P2.jl:97), as data: (row, value) lists per parent basis function, 1-based rows
+# = 7*(child-1) + child node.  It is the parent's P2+bubble basis evaluated at the child nodes
+# EXCEPT for the six rows of child mid-edge nodes that lie inside the parent, where the reference
+# carries integer-rounded numerators (61, 80, -20, -82, 549 for the exact 60.75, 81, -20.25, -81,
+# 546.75; the rows still sum to one and still reproduce linears).  tests/test_geometric_mg.py checks both facts.
+_REFINE_BUBBLE_648 = (
+    ((2, 243), (3, 648), (4, 243), (6, 61), (7, 180), (9, -81), (13, -20), (14, -36), (18, -81), (20, -20), (21, -36), (23, -20), (25, -20), (27, 61)),
+    ((4, 486), (5, 648), (6, 80), (7, 144), (8, 648), (9, 486), (13, 80), (14, 144), (20, -82), (21, -72), (22, 648), (23, 80), (25, -82), (27, 80)),
+    ((4, -81), (6, -20), (7, -36), (9, 243), (10, 648), (11, 243), (13, 61), (14, 180), (16, -81), (20, -20), (21, -36), (23, 61), (25, -20), (27, -20)),
+    ((6, -82), (7, -72), (11, 486), (12, 648), (13, 80), (14, 144), (15, 648), (16, 486), (20, 80), (21, 144), (23, 80), (24, 648), (25, 80), (27, -82)),
+    ((2, -81), (6, -20), (7, -36), (11, -81), (13, -20), (14, -36), (16, 243), (17, 648), (18, 243), (20, 61), (21, 180), (23, -20), (25, 61), (27, -20)),
+    ((1, 648), (2, 486), (6, 80), (7, 144), (13, -82), (14, -72), (18, 486), (19, 648), (20, 80), (21, 144), (23, -82), (25, 80), (26, 648), (27, 80)),
+    ((6, 549), (7, 324), (13, 549), (14, 324), (20, 549), (21, 324), (23, 549), (25, 549), (27, 549), (28, 648)),
+)
+
+
+def refine_table(bubble: bool = True) -> np.ndarray:
+    """(4V x V) child-interpolation table.  bubble: the reference's table (see above); pure P2: the
+    P2 basis evaluated at the child nodes (exact; reference: src/fem2d_P2.jl:129-131)."""
+    if bubble:
+        T = np.zeros((28, 7))
+        for j, col in enumerate(_REFINE_BUBBLE_648):
+            for (r, v) in col:
+                T[r - 1, j] = v / 648.0
+        return T
+    # P2: phi_i at the child nodes, barycentric closed forms l(2l-1) / 4 l_a l_b
+    nodes = _bary_nodes(False)
+    T = np.zeros((24, 6))
+    for s_, cc in enumerate(_CHILD_CORNERS):
+        corners = [nodes[c] for c in cc]
+        for v, nd in enumerate(nodes):
+            lam = [sum(nd[c] * corners[c][k] for c in range(3)) for k in range(3)]
+            vals = [lam[0] * (2 * lam[0] - 1), 4 * lam[0] * lam[1], lam[1] * (2 * lam[1] - 1), 4 * lam[1] * lam[2],
+                    lam[2] * (2 * lam[2] - 1), 4 * lam[2] * lam[0]]
+            T[6 * s_ + v] = [float(x) for x in vals]
+    return T
+
+
+def continuous(t: np.ndarray) -> sp.csr_matrix:
+    """reference: src/fem2d_P2.jl:159-163 (zero-trace continuous space of one level)."""
+    labels = t.T.reshape(-1)
+    bdry = _p2_boundary_dedup_set(labels, t.shape[1])
+    return continuous_subspace(labels, int(labels.max()) + 1, bdry)
+
+
+def geometric_mg(geom: Geometry, L: int) -> MultiGrid:
+    """`geometric_mg(geom, L)`: L levels of red refinement with the element-local transfer table
+    (reference: src/fem2d_P2.jl:468-596).  Per level: continuous zero-trace P2(+bubble), broken identity,
+    constants and the broken-P1 rider."""
+    from .multigrid import make_multigrid
+    from .tensorfem import _vblock_refine
+    if not isinstance(geom.discretization, FEM2D_P2):
+        raise TypeError("geometric_mg: FEM2D_P2 geometry expected")
+    if L < 1:
+        raise ValueError("L must be >= 1")
+    p = geom.x.shape[0]
+    T = refine_table(p == 7)
+    X, t = geom.x, geom.t
+    topo, sizes = [t], [X.shape[1]]
+    for _ in range(L - 1):
+        t = _refine_p2_connectivity(t)
+        topo.append(t)
+        sizes.append(4 * sizes[-1])
+    refine = [_vblock_refine(T, p, 4, sizes[l]) for l in range(L - 1)]
+    refine.append(sp.identity(p * sizes[-1], format="csr"))
+    # fine coordinates: x[l+1] = refine[l] * x[l] like the reference (src/fem2d_P2.jl:513)
+    xf = X.transpose(1, 0, 2).reshape(-1, X.shape[2])
+    for l in range(L - 1):
+        xf = refine[l] @ xf
+    Kfine = xf.reshape(sizes[-1], p, X.shape[2]).transpose(1, 0, 2)
+    geomL = _build_geometry(np.ascontiguousarray(Kfine), topo[-1])
+    subspaces = {"dirichlet": [], "full": [], "uniform": [], "broken_P1": []}
+    for l in range(L):
+        nl = p * sizes[l]
+        subspaces["dirichlet"].append(continuous(topo[l]))
+        subspaces["full"].append(sp.identity(nl, format="csr"))
+        subspaces["uniform"].append(sp.csr_matrix(np.ones((nl, 1))))
+        subspaces["broken_P1"].append(_broken_p1_embedding(sizes[l], p))
+    return make_multigrid(geomL, subspaces, refine)

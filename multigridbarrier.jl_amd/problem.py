@@ -122,6 +122,18 @@ def subdivide(geom: Geometry, L: int) -> Geometry:
     raise TypeError(f"subdivide: unsupported discretization {type(disc).__name__}")
 
 
+def geometric_mg(geom: Geometry, L: int) -> MultiGrid:
+    """reference: `geometric_mg`, src/multigrid.jl:422-431 (spectral discretizations ignore L and return `amg`)."""
+    disc = geom.discretization
+    if isinstance(disc, fem2d_p2.FEM2D_P2):
+        return fem2d_p2.geometric_mg(geom, L)
+    if isinstance(disc, tensorfem.TensorFEM):
+        return tensorfem.geometric_mg(geom, L)
+    if isinstance(disc, (spectral.SPECTRAL1D, spectral.SPECTRAL2D)):
+        return spectral.amg(geom)
+    raise TypeError(f"geometric_mg: unsupported discretization {type(disc).__name__}")
+
+
 def find_boundary(geom: Geometry):
     disc = geom.discretization
     if isinstance(disc, fem2d_p2.FEM2D_P2):

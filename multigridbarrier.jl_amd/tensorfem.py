@@ -497,3 +497,61 @@ def subdivide(geom: Geometry, L: int) -> Geometry:
         X = Xf.reshape(n, -1, X.shape[2])                          # element-major, child fastest
         t = _tf_refine_connectivity(t, k, d)
     return _tf_build_geometry(d, disc.e, k, X, t)
+
+
+def _vblock_refine(P_local: np.ndarray, n: int, nc: int, n_elems: int) -> sp.csr_matrix:
+    """The level transfer as a sparse matrix: child block (e*nc + ch) of the fine broken basis reads the
+    n x n table P_local[ch] from parent block e (reference: `_vblock_sparse(n, n, nc, n_elems, ref_data)`,
+    src/TensorFEM.jl:930-936 / src/fem2d_P2.jl:503-512).  Structural zeros of the table are dropped like
+    the reference's sparse storage drops them."""
+    blocks = P_local.reshape(nc, n, n)
+    ch, i, j = np.nonzero(blocks)
+    v = blocks[ch, i, j]
+    e = np.arange(n_elems)
+    rows = ((e[:, None] * nc + ch[None, :]) * n + i[None, :]).reshape(-1)
+    cols = (e[:, None] * n + j[None, :]).reshape(-1)
+    out = sp.csr_matrix((np.tile(v, n_elems), (rows, cols)), shape=(n * nc * n_elems, n * n_elems))
+    out.sort_indices()
+    return out
+
+
+def _tf_continuous_subspace(X: np.ndarray, t: np.ndarray, k: int, d: int) -> sp.csr_matrix:
+    """reference: src/TensorFEM.jl:804-815 (zero-trace continuous Q_k space of one level)."""
+    disc = TensorFEM(d=d, e=X.shape[2], k=k, K=np.zeros((1 << d, 0, X.shape[2])))
+    geomlike = Geometry(disc, t, X, np.zeros(0), {})
+    labels = geomlike.labels
+    n = (k + 1) ** d
+    bset = {int(labels[v + e * n]) for (v, e) in find_boundary(geomlike)}
+    return continuous_subspace(labels, int(labels.max()) + 1, bset)
+
+
+def geometric_mg(geom: Geometry, L: int) -> MultiGrid:
+    """`geometric_mg(geom, L)`: the L-level geometric-subdivision hierarchy of the tensor family
+    (reference: src/TensorFEM.jl:888-954): per level the continuous zero-trace space, the broken
+    identity and the constant; level transfers are the element-local 2^d-child interpolation tables."""
+    from .multigrid import make_multigrid
+    disc = geom.discretization
+    if not isinstance(disc, TensorFEM):
+        raise TypeError("geometric_mg: TensorFEM geometry expected")
+    if L < 1:
+        raise ValueError("L must be >= 1")
+    d, k = disc.d, disc.k
+    n = (k + 1) ** d
+    nc = 1 << d
+    P_local = _tf_refine_local(k, d)
+    meshes, topo = [geom.x], [geom.t]
+    for _ in range(L - 1):
+        X = meshes[-1]
+        Xf = np.einsum("cij,jed->iecd", P_local.reshape(nc, n, n), X)
+        meshes.append(Xf.reshape(n, -1, X.shape[2]))
+        topo.append(_tf_refine_connectivity(topo[-1], k, d))
+    geomL = geom if L == 1 else _tf_build_geometry(d, disc.e, k, meshes[-1], topo[-1])
+    refine = [_vblock_refine(P_local, n, nc, meshes[l].shape[1]) for l in range(L - 1)]
+    refine.append(sp.identity(n * meshes[-1].shape[1], format="csr"))
+    subspaces = {"dirichlet": [], "full": [], "uniform": []}
+    for l in range(L):
+        nl = n * meshes[l].shape[1]
+        subspaces["dirichlet"].append(_tf_continuous_subspace(meshes[l], topo[l], k, d))
+        subspaces["full"].append(sp.identity(nl, format="csr"))
+        subspaces["uniform"].append(sp.csr_matrix(np.ones((nl, 1))))
+    return make_multigrid(geomL, subspaces, refine)

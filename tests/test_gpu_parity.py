@@ -587,3 +587,26 @@ def test_user_stopping_criterion_and_early_stop_callables():
     assert sol_e.SOL_main["ts"][-1] < base.SOL_main["ts"][-1]            # stopped before 1/tol
     assert np.allclose(sol_e.SOL_main["ts"], ref_e["SOL_main"]["ts"])
     assert np.abs(sol_e.z - ref_e["z"]).max() < 1e-8 and s_of(stacked(sol_e.z)).max() < 8.0
+
+
+# the nine CPU-vs-device cases of the reference's CUDA extension test (test/test_cuda.jl:34-56); fem2d_P1 is
+# outside this package's scope (no hot-path role), the other eight run device vs oracle
+CUDA_EXT_CASES = {
+    "fem1d geometric_mg": lambda: m.assemble(m.geometric_mg(m.fem1d(nodes=np.linspace(-1.0, 1.0, 9)), 3)),
+    "fem2d_P2 geometric_mg": lambda: m.assemble(m.geometric_mg(m.fem2d_P2(), 3)),
+    "fem3d geometric_mg": lambda: m.assemble(m.geometric_mg(m.fem3d(k=3), 2)),
+    "spectral1d": lambda: m.assemble(m.amg(m.spectral1d(n=8))),
+    "spectral2d": lambda: m.assemble(m.amg(m.spectral2d(n=5))),
+    "fem1d AMG": lambda: m.assemble(m.amg(m.fem1d(nodes=np.linspace(-1.0, 1.0, 5))), p=1.0),
+    "fem2d_P2 AMG": lambda: m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 2)), p=1.0),
+    "fem3d AMG": lambda: m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 2)), p=1.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CUDA_EXT_CASES))
+def test_reference_cuda_extension_cases_device_vs_cpu(name):
+    prob = CUDA_EXT_CASES[name]()
+    sol = m.mgb_solve(prob)
+    ref = O.mgb_solve(prob)
+    assert np.abs(sol.z - ref["z"]).max() < 1e-8                        # the reference's criterion (test/test_cuda.jl:51)
+    assert "mgb_solve: device = HIPDevice" in sol.log
