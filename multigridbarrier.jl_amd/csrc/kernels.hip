@@ -1151,7 +1151,11 @@ void launch_panel_project_staged(const PanelParams& P, int32_t ctmax, hipStream_
 void launch_panel_project(const PanelParams& P, hipStream_t st) {
     if (P.N == 0) return;
     const size_t lds = (size_t)4 * P.p * P.cmax * sizeof(double);
-    MGB_REQUIRE(lds <= 64 * 1024, "coarse-level panels too wide for the projection kernel");
+    // 64-node elements with full-width panels (fem3d k = 3 on a geometric ladder) need 128 KB: opt in once
+    static const bool big_lds = hipFuncSetAttribute((const void*)panel_project_kernel,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess;
+    if (!big_lds) (void)hipGetLastError();
+    MGB_REQUIRE(lds <= (big_lds ? 144 : 64) * 1024, "coarse-level panels too wide for the projection kernel");
     hipLaunchKernelGGL(panel_project_kernel, dim3((unsigned)((P.N + 3) / 4)), dim3(256), lds, st, P);
     MGB_HIP_CHECK(hipGetLastError());
 }
