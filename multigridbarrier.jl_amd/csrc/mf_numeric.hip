@@ -98,82 +98,6 @@ __device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NBT], int nb, int lan
     return bad;
 }
 
-// Same factorization with the pivot chain software-pipelined: column j+1 is updated first and its
-// reciprocal pivot is started before the bulk of column j's updates, so the long rcp + Newton
-// latency hides behind the broadcast/FMA stream instead of standing between two columns.
-template <int NBT>
-__device__ __forceinline__ bool wave_ldlt_pipe(double (&a)[NBT], int nb, int lane) {
-    bool bad = false;
-    double d = readlane_f64(a[0], 0);
-    if (d == 0.0 || !isfinite(d)) bad = true;
-    double inv = fast_recip(d);
-#pragma unroll
-    for (int j = 0; j < NBT; ++j) {
-        if (j < nb) {
-            const double aj = a[j];
-            const double lr = aj * inv;
-            double inv_next = 1.0;
-            if (j + 1 < NBT) {
-                a[j + 1] -= lr * readlane_f64(aj, j + 1);
-                if (j + 1 < nb) {
-                    const double dn = readlane_f64(a[j + 1], j + 1);
-                    if (dn == 0.0 || !isfinite(dn)) bad = true;
-                    inv_next = fast_recip(dn);
-                }
-            }
-#pragma unroll
-            for (int c = j + 2; c < NBT; ++c) a[c] -= lr * readlane_f64(aj, c);
-            if (lane > j) a[j] = lr;
-            inv = inv_next;
-        }
-    }
-    return bad;
-}
-
-#ifdef MGB_STEP_PROBE
-__device__ long long g_probe[64];
-#endif
-// LDL' of a 32 x 32 block by one wave with the multiplier columns broadcast through LDS instead of
-// v_readlane (a readlane + dependent FMA pair costs ~35 cycles on gfx950; a broadcast ds_read_b128
-// delivers two multipliers per issue slot).  Lane r (and its twin r + 32) holds row r in registers.
-// Column j+1 is brought up to date first, published to the other LDS buffer and its reciprocal pivot
-// started, then the remaining columns take the rank-1 update of column j: the pivot chain and the
-// LDS round trip hide behind the bulk FMAs.  colbuf: 2 x 32 doubles, 16-byte aligned.
-__device__ __forceinline__ bool wave_ldlt_lds32(double (&a)[NB], int nb, int lane, double* colbuf) {
-    bool bad = false;
-    const int r = lane & 31;
-    if (lane < 32) colbuf[r] = a[0];
-    double d = readlane_f64(a[0], 0);
-    if (d == 0.0 || !isfinite(d)) bad = true;
-    double inv = fast_recip(d);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if (j < nb) {
-            const double* cb = colbuf + 32 * (j & 1);
-            double* cn = colbuf + 32 * ((j + 1) & 1);
-            const double aj = a[j];
-            const double lr = aj * inv;
-            double inv_next = 1.0;
-            if (j + 1 < NB) {
-                a[j + 1] -= lr * readlane_f64(aj, j + 1);      // the one multiplier on the pivot chain: no LDS round trip
-                if (lane < 32) cn[r] = a[j + 1];
-                if (j + 1 < nb) {
-                    const double dn = readlane_f64(a[j + 1], j + 1);
-                    if (dn == 0.0 || !isfinite(dn)) bad = true;
-                    inv_next = fast_recip(dn);
-                }
-            }
-#pragma unroll
-            for (int c = j + 2; c < NB; ++c) a[c] -= lr * cb[c];
-            if (r > j) a[j] = lr;
-            inv = inv_next;
-            // no wait here: the LDS unit executes one wave's operations in order, so the reads of the
-            // next column queue behind the write above while the reciprocal chain runs
-        }
-    }
-    return bad;
-}
-
 // One workgroup per front.  Right-looking LDL' blocked by NB = 32 columns: wave 0 factors the
 // diagonal block in registers (shuffles only), every thread then solves one panel row in
 // registers, and all threads apply the rank-32 update -- 3 workgroup barriers per 32 columns.
@@ -1193,26 +1117,101 @@ constexpr int BIGI_THREADS = 1024;
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// Wave 0 only (rows on lanes 0..31): LDL' of the nb x nb lower block in Dn (row-major [r][c]).  On
-// return Dn holds the strictly lower unit factor L (zero elsewhere, identity rows beyond nb) and
-// dq the pivots (1 beyond nb).
-__device__ __forceinline__ void wave_ldlt_lds(double (*Dn)[NB + 1], double* dq, int nb, int lane,
-                                              int32_t* __restrict__ status, double* colbuf) {
-    double d[NB];
-    const int rl = lane & 31;
-#pragma unroll
-    for (int c = 0; c < NB; ++c) d[c] = (rl < nb && c <= rl) ? Dn[rl][c] : 0.0;
-    const bool bad = wave_ldlt_lds32(d, nb, lane, colbuf);
-    if (bad && lane == 0 && status) atomicOr(status, 1);
-    if (lane < NB) {
-        double piv = 1.0;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            Dn[lane][c] = (c < lane && lane < nb) ? d[c] : 0.0;
-            if (c == lane && lane < nb) piv = d[c];
+// Blocked LDL' of the 32 x 32 block in Dn (row-major lower triangle, in LDS) by the whole workgroup.
+// Every cross-thread hand-off on this chip costs several hundred cycles (measured: ~600 cycles per
+// column for a one-column-at-a-time factorization, whether one wave keeps the rows in registers or eight
+// half-waves share the columns), so the pivot recurrence runs four columns at a time inside ONE lane:
+//   serial   lane 0: LDL' of the 4 x 4 diagonal block, its unit-lower inverse W4 and 1/d    (registers only)
+//   phase A  rows below the block: s = a W4', l = s / d; l is final, (s, l) go to the panel buffers
+//   phase B  trailing update  a(r, c) -= sum_k s(r, k) l(c, k);  the next 4 x 4 diagonal block is taken by
+//            ten lanes of wave 0, and lane 0 factors it at once while the other waves finish the update
+// -> two workgroup barriers per four columns.  On return Dn holds the strictly lower unit factor (zeros
+// elsewhere, identity beyond nb), dq the pivots (1 beyond nb).  Every thread of the workgroup must call this.
+struct Blk4 { double w10, w20, w21, w30, w31, w32, i0, i1, i2, i3, d0, d1, d2, d3; };
+
+__device__ __forceinline__ bool ldlt4_serial(double a00, double a10, double a11, double a20, double a21, double a22, double a30,
+                                             double a31, double a32, double a33, Blk4& B, double (&l)[6]) {
+    const double d0 = a00, i0 = fast_recip(d0);
+    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    const double d1 = a11 - l10 * a10, i1 = fast_recip(d1);
+    const double t21 = a21 - l20 * a10, t31 = a31 - l30 * a10;
+    const double l21 = t21 * i1, l31 = t31 * i1;
+    const double d2 = a22 - l20 * a20 - l21 * t21, i2 = fast_recip(d2);
+    const double t32 = a32 - l30 * a20 - l31 * t21;
+    const double l32 = t32 * i2;
+    const double d3 = a33 - l30 * a30 - l31 * t31 - l32 * t32, i3 = fast_recip(d3);
+    B.d0 = d0; B.d1 = d1; B.d2 = d2; B.d3 = d3;
+    B.i0 = i0; B.i1 = i1; B.i2 = i2; B.i3 = i3;
+    B.w10 = -l10; B.w21 = -l21; B.w32 = -l32;
+    B.w20 = l21 * l10 - l20;
+    B.w31 = l32 * l21 - l31;
+    B.w30 = l31 * l10 + l32 * (l20 - l21 * l10) - l30;
+    l[0] = l10; l[1] = l20; l[2] = l21; l[3] = l30; l[4] = l31; l[5] = l32;
+    const double dmin = fmin(fmin(fabs(d0), fabs(d1)), fmin(fabs(d2), fabs(d3)));
+    return !(dmin > 0.0) || !isfinite(d0) || !isfinite(d1) || !isfinite(d2) || !isfinite(d3);
+}
+
+__device__ __forceinline__ void block_ldlt32_b4(double (*Dn)[NB + 1], double* dq, int nb, int tid, double* Wb /* [2][16] */,
+                                                double (*Sp)[4], double (*Lp)[4], int32_t* __restrict__ status) {
+    const int r = tid & 31, cg = tid >> 5;
+    // identity padding beyond nb keeps the 4 x 4 recurrences free of special cases
+    if (tid < NB && tid >= nb) Dn[tid][tid] = 1.0;
+    __syncthreads();
+    auto serial = [&](int cb, int buf) {      // lane 0 only: factor the diagonal block at cb, publish W4 / d / 1/d and L11
+        Blk4 B;
+        double l[6];
+        const bool bad = ldlt4_serial(Dn[cb][cb], Dn[cb + 1][cb], Dn[cb + 1][cb + 1], Dn[cb + 2][cb], Dn[cb + 2][cb + 1],
+                                      Dn[cb + 2][cb + 2], Dn[cb + 3][cb], Dn[cb + 3][cb + 1], Dn[cb + 3][cb + 2],
+                                      Dn[cb + 3][cb + 3], B, l);
+        if (bad && status) atomicOr(status, 1);
+        double* w = Wb + 16 * buf;
+        w[0] = B.w10; w[1] = B.w20; w[2] = B.w21; w[3] = B.w30; w[4] = B.w31; w[5] = B.w32;
+        w[6] = B.i0; w[7] = B.i1; w[8] = B.i2; w[9] = B.i3;
+        dq[cb] = B.d0; dq[cb + 1] = B.d1; dq[cb + 2] = B.d2; dq[cb + 3] = B.d3;
+        Dn[cb + 1][cb] = l[0]; Dn[cb + 2][cb] = l[1]; Dn[cb + 2][cb + 1] = l[2];
+        Dn[cb + 3][cb] = l[3]; Dn[cb + 3][cb + 1] = l[4]; Dn[cb + 3][cb + 2] = l[5];
+    };
+    if (tid == 0) serial(0, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int b = 0; b < NB / 4; ++b) {
+        const int cb = 4 * b, cn = cb + 4;
+        const double* w = Wb + 16 * (b & 1);
+        // phase A: panel rows
+        if (tid < NB && tid >= cn) {
+            const double a0 = Dn[tid][cb], a1 = Dn[tid][cb + 1], a2 = Dn[tid][cb + 2], a3 = Dn[tid][cb + 3];
+            const double s0 = a0;
+            const double s1 = a1 + a0 * w[0];
+            const double s2 = a2 + a0 * w[1] + a1 * w[2];
+            const double s3 = a3 + a0 * w[3] + a1 * w[4] + a2 * w[5];
+            const double l0 = s0 * w[6], l1 = s1 * w[7], l2 = s2 * w[8], l3 = s3 * w[9];
+            Dn[tid][cb] = l0; Dn[tid][cb + 1] = l1; Dn[tid][cb + 2] = l2; Dn[tid][cb + 3] = l3;
+            Sp[tid][0] = s0; Sp[tid][1] = s1; Sp[tid][2] = s2; Sp[tid][3] = s3;
+            Lp[tid][0] = l0; Lp[tid][1] = l1; Lp[tid][2] = l2; Lp[tid][3] = l3;
         }
-        dq[lane] = piv;
+        __syncthreads();
+        if (cn >= NB) break;
+        // phase B: next diagonal block first (ten lanes of wave 0, then lane 0 alone), trailing update elsewhere
+        if (tid < 10) {
+            const int rr = tid < 1 ? 0 : (tid < 3 ? 1 : (tid < 6 ? 2 : 3));
+            const int cc = tid - rr * (rr + 1) / 2;
+            const int R = cn + rr, C = cn + cc;
+            Dn[R][C] -= Sp[R][0] * Lp[C][0] + Sp[R][1] * Lp[C][1] + Sp[R][2] * Lp[C][2] + Sp[R][3] * Lp[C][3];
+        }
+        if (tid < 64) wave_sync();
+        if (tid == 0) serial(cn, (b + 1) & 1);
+        if (r >= cn + 4) {                      // rows below the next diagonal block
+            for (int c = cn + cg; c <= r; c += 8)
+                Dn[r][c] -= Sp[r][0] * Lp[c][0] + Sp[r][1] * Lp[c][1] + Sp[r][2] * Lp[c][2] + Sp[r][3] * Lp[c][3];
+        }
+        __syncthreads();
     }
+    // strictly lower L only: clear the diagonal and everything above it
+    for (int i = tid; i < NB * NB; i += 256) {
+        const int rr = i / NB, cc = i % NB;
+        if (cc >= rr || rr >= nb) Dn[rr][cc] = 0.0;
+    }
+    __syncthreads();
 }
 
 // W = L^{-1} for the unit lower triangular 32 x 32 L in Ls (strictly lower part, row-major), all 256
@@ -1292,7 +1291,8 @@ __device__ __forceinline__ void slice_transform(double (*P)[ST + 1], double (*Po
     }
 }
 
-#ifdef MGB_STEP_PROBE
+#ifdef MGB_STEP_PROBE      // development probe build only (tools/gpu_probe.py): per-phase timestamps of one step
+__device__ long long g_probe[64];
 #define PROBE(i) do { if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[i] = wall_clock64(); if (!is_la && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[16 + i] = wall_clock64(); } while (0)
 #else
 #define PROBE(i) do { } while (0)
@@ -1306,7 +1306,8 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
     __shared__ double Dn[NB][NB + 1];
     __shared__ double Tm[16][17];
     __shared__ double dq[NB], rdq[NB];
-    __shared__ __attribute__((aligned(16))) double colbuf[2 * NB];
+    __shared__ __attribute__((aligned(16))) double colbuf[4 * NB];
+    __shared__ double Sp4[NB][4], Lp4[NB][4];
     __shared__ double Pa[NB][ST + 1];
     __shared__ double Pb[NB][ST + 1];
     const FrontDev F = fr[first + blockIdx.y];
@@ -1368,8 +1369,7 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
             Dn[rr][c] = (rr >= c && rr < nb) ? W[(j0 + rr) + (int64_t)(j0 + c) * m] : 0.0;
         }
         __syncthreads();
-        if (tid < 64) wave_ldlt_lds(Dn, dq, nb, tid, is_la ? status : nullptr, colbuf);
-        __syncthreads();
+        block_ldlt32_b4(Dn, dq, nb, tid, colbuf, Sp4, Lp4, is_la ? status : nullptr);
         block_inverse32(Dn, Wv, Tm, tid);
     } else {
         for (int i = tid; i < NB * NB; i += 256) {
@@ -1429,11 +1429,10 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
 #ifdef MGB_STEP_PROBE
         if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[32] = clock64();
 #endif
-        if (tid < 64) wave_ldlt_lds(Dn, dq, nbn, tid, status, colbuf);
+        block_ldlt32_b4(Dn, dq, nbn, tid, colbuf, Sp4, Lp4, status);
 #ifdef MGB_STEP_PROBE
         if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[33] = clock64();
 #endif
-        __syncthreads();
         PROBE(5);
         block_inverse32(Dn, Wv, Tm, tid);
         PROBE(6);

@@ -370,7 +370,8 @@ void mgbhip_problem::ensure_plan(int level) {
         L.acc_chunk = (int32_t)chunk;
         // wide coarse supports only (3-D hierarchies): many contributions per entry, few enough
         // elements per stream; narrow supports are faster through slab + gather
-        L.acc = !selection && m > 0 && m <= ACC_MAX_M && room > 0 && nsplit <= 4 && NE <= 65536 && slab_est >= 16 * mt &&
+        static const int64_t acc_ne_max = [] { const char* e = getenv("MGBHIP_ACC_NE_MAX"); return e ? atoll(e) : 65536ll; }();
+        L.acc = !selection && m > 0 && m <= ACC_MAX_M && room > 0 && nsplit <= 4 && NE <= acc_ne_max && slab_est >= 16 * mt &&
                 panel_accumulate_fits(pp, nu, (int)ctmax);
         if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
             fprintf(stderr, "[mgbhip] assembly plan level %d: m=%lld selection=%d cmax=%d slab=%lld doubles, accumulators=%lld -> %s\n", level,
