@@ -1492,17 +1492,52 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
     PROBE(4);
 }
 
+// First diagonal block of every front of a batch, factored and inverted once (one workgroup per front)
+// into slot 0.  Used for batches of many fronts, where the redundant factorization inside every trailing
+// tile of step 0 (do_diag) would occupy all compute units with copies of the same 32 x 32 problem.
+__global__ __launch_bounds__(256) void mf_big_diag0(const FrontDev* __restrict__ fr, int32_t first,
+                                                    const double* __restrict__ arena, double* __restrict__ dscr,
+                                                    int32_t* __restrict__ status) {
+    __shared__ double Wv[NB][NB + 1];
+    __shared__ double Dn[NB][NB + 1];
+    __shared__ double Tm[16][17];
+    __shared__ double dq[NB];
+    __shared__ __attribute__((aligned(16))) double colbuf[4 * NB];
+    __shared__ double Sp4[NB][4], Lp4[NB][4];
+    const FrontDev F = fr[first + blockIdx.x];
+    const int m = F.m, nb = min(NB, F.k), tid = threadIdx.x;
+    const double* W = arena + F.F_off;
+    for (int i = tid; i < NB * NB; i += 256) {
+        const int rr = i % NB, c = i / NB;
+        Dn[rr][c] = (rr >= c && rr < nb) ? W[rr + (int64_t)c * m] : 0.0;
+    }
+    __syncthreads();
+    block_ldlt32_b4(Dn, dq, nb, tid, colbuf, Sp4, Lp4, status);
+    block_inverse32(Dn, Wv, Tm, tid);
+    double* slot = dscr + (int64_t)blockIdx.x * 2 * (NB * NB);
+    for (int i = tid; i < NB * NB; i += 256) {
+        const int rr = i % NB, c = i / NB;
+        if (rr >= c && rr < nb) slot[rr + NB * c] = (rr == c) ? dq[rr] : Wv[rr][c];
+    }
+}
+
 // ---- triangular solves on the inverse-based layout: one workgroup per front --------------------
 // forward:  y' = L^{-1} t by blocks:  y'_j = W_j t_j,  u = W_j' D_j^{-1} y'_j,  t[r] -= A[r, j] u  (r below)
 __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __restrict__ fr, int32_t first,
                                                            const int32_t* __restrict__ front_idx,
-                                                           const int32_t* __restrict__ children,
-                                                           const int32_t* __restrict__ rel,
+                                                           const int64_t* __restrict__ ug_ptr,
+                                                           const int64_t* __restrict__ ug_src,
                                                            const double* __restrict__ arena,
                                                            const double* __restrict__ dvec,
                                                            const double* __restrict__ b, double* __restrict__ y,
                                                            double* __restrict__ uvec) {
     extern __shared__ double sh[];
+#ifdef MGB_STEP_PROBE
+#define FP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && gridDim.x > 150) g_probe[48 + i] = wall_clock64(); } while (0)
+#else
+#define FP(i) do { } while (0)
+#endif
+    FP(0);
     const FrontDev F = fr[first + blockIdx.x];
     const int m = F.m, k = F.k;
     const int tid = threadIdx.x, nt = BIGI_THREADS;
@@ -1510,64 +1545,105 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __res
     double* Wl = sh + ((m + 1) & ~1);              // [NB][NB + 1]
     double* dl = Wl + NB * (NB + 1);               // [NB]
     double* uq = dl + NB;                          // [NB]
+    double* part = uq + NB;                        // [BIGI_THREADS] partial sums of the column-split row update
     const int32_t* idx = front_idx + F.idx_off;
     const double* Fm = arena + F.F_off;
     const double* dv = dvec + F.idx_off;
-    for (int j = tid; j < m; j += nt) tl[j] = (j < k) ? b[idx[j]] : 0.0;
-    __syncthreads();
-    for (int c = 0; c < F.nchild; ++c) {
-        const FrontDev C = fr[children[F.child_off + c]];
-        const int32_t* rl = rel + C.rel_off;
-        const double* uc = uvec + C.u_off;
-        const int bc = C.m - C.k;
-        for (int j = tid; j < bc; j += nt) tl[rl[j]] += uc[j];
-        __syncthreads();
+    {   // t = [b(piv); 0] + the children's update vectors: one gather per entry, contributions in child order
+        const int64_t* up = ug_ptr + F.ug_off;
+        for (int j = tid; j < m; j += nt) {
+            double v = (j < k) ? b[idx[j]] : 0.0;
+            for (int64_t e = up[j]; e < up[j + 1]; ++e) v += uvec[ug_src[e]];
+            tl[j] = v;
+        }
     }
     const int wa = tid % NB, wb = tid / NB;          // W_j[q = wb][c = wa] sits at (j0 + wa, j0 + wb), wa < wb
     double wnext = (wa < wb && wb < k) ? Fm[wa + (int64_t)wb * m] : 0.0;
+    double dnext = (tid < NB && tid < k) ? dv[tid] : 1.0;
+    __syncthreads();
+    FP(1);
     for (int j0 = 0; j0 < k; j0 += NB) {
         const int nb = min(NB, k - j0), j1 = j0 + nb;
-        Wl[wb * (NB + 1) + wa] = (wa < wb) ? wnext : (wa == wb ? 1.0 : 0.0);
-        if (tid < NB) dl[tid] = (tid < nb) ? dv[j0 + tid] : 1.0;
+        Wl[wb * (NB + 1) + wa] = (wa < wb) ? wnext : (wa == wb ? 1.0 : 0.0);      // zero upper part: fixed-length dots below
+        if (tid < NB) dl[tid] = dnext;
         __syncthreads();
+        FP(2);
         {
             const int jn = j0 + NB;
             wnext = (wa < wb && jn + wb < k) ? Fm[(jn + wa) + (int64_t)(jn + wb) * m] : 0.0;
+            dnext = (tid < NB && jn + tid < k) ? dv[jn + tid] : 1.0;
         }
-        if (tid < 64) {
-            const int q = tid & 31;
-            double v = 0.0;
-            if (q < nb)
-                for (int c = 0; c <= q; ++c) v += Wl[q * (NB + 1) + c] * tl[j0 + c];
-            wave_sync();
-            if (tid < nb) tl[j0 + tid] = v;                       // y'_j
-            const double vs = (q < nb) ? v / dl[q] : 0.0;
-            uq[q] = vs;                                           // both half-waves write the same values
-            wave_sync();
-            double u = 0.0;
-            if (q < nb)
-                for (int qq = q; qq < nb; ++qq) u += Wl[qq * (NB + 1) + q] * uq[qq];
-            wave_sync();
-            if (tid < NB) uq[tid] = (tid < nb) ? u : 0.0;
-        }
-        __syncthreads();
-        for (int r = j1 + tid; r < m; r += nt) {
-            const double* Ar = Fm + r + (int64_t)j0 * m;
-            double v = 0.0;
-            if (nb == NB) {
+        {   // the two 32 x 32 triangular products on all 1024 threads: thread (q, c) forms one term, a 32-lane
+            // butterfly sums the row -- two LDS round trips instead of two 32-step serial dots in one wave
+            const int q = tid >> 5, c = tid & 31;
+            double pr = Wl[q * (NB + 1) + c] * (c < nb ? tl[j0 + c] : 0.0);        // W is unit lower, zero above
 #pragma unroll
-                for (int c = 0; c < NB; ++c) v += Ar[(int64_t)c * m] * uq[c];
-            } else {
-                for (int c = 0; c < nb; ++c) v += Ar[(int64_t)c * m] * uq[c];
+            for (int off = 16; off > 0; off >>= 1) pr += __shfl_xor(pr, off, 32);
+            __syncthreads();                                                      // every term has read t_j
+            if (c == 0 && q < nb) {
+                tl[j0 + q] = pr;                                                  // y'_j
+                uq[q] = pr / dl[q];
+            } else if (c == 0) {
+                uq[q] = 0.0;
             }
-            tl[r] -= v;
+            __syncthreads();
+            double pu = Wl[c * (NB + 1) + q] * uq[c];                             // u[q] = sum_c W[c][q] (y'/d)[c]
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) pu += __shfl_xor(pu, off, 32);
+            __syncthreads();
+            if (c == 0) uq[q] = (q < nb) ? pu : 0.0;
         }
         __syncthreads();
+        FP(3);
+        {   // rows below the block: t[r] -= A[r, j0 .. j1) u.  The panel is column-major, so a thread's 32 terms are
+            // 32 strided loads; they are issued eight at a time (a rolled loop waits one memory latency per term,
+            // a 32-way unroll spills at 1024 threads), and fronts with few rows split the columns over G thread
+            // groups so that all 1024 threads carry loads; the partial sums meet in LDS in a fixed order.
+            const int rows = m - j1;
+            int G = 1;
+            while (G < 8 && 2 * G * rows <= nt) G *= 2;
+            if (rows > 0 && G == 1) {
+                for (int r = j1 + tid; r < m; r += nt) {
+                    const double* Ar = Fm + r + (int64_t)j0 * m;
+                    double v = 0.0;
+                    for (int c0 = 0; c0 < nb; c0 += 8) {
+                        double a[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) a[u] = Ar[(int64_t)min(c0 + u, nb - 1) * m];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v += a[u] * uq[c0 + u];          // uq is zero beyond nb
+                    }
+                    tl[r] -= v;
+                }
+            } else if (rows > 0) {
+                const int cgp = tid / rows, rr = tid - cgp * rows;
+                if (cgp < G) {
+                    const double* Ar = Fm + (j1 + rr) + (int64_t)j0 * m;
+                    double a[4], v = 0.0;
+                    for (int c0 = cgp; c0 < nb; c0 += 4 * G) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a[u] = Ar[(int64_t)min(c0 + u * G, nb - 1) * m];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v += a[u] * (c0 + u * G < nb ? uq[c0 + u * G] : 0.0);
+                    }
+                    part[cgp * rows + rr] = v;
+                }
+                __syncthreads();
+                if (tid < rows) {
+                    double v = 0.0;
+                    for (int gg = 0; gg < G; ++gg) v += part[gg * rows + tid];
+                    tl[j1 + tid] -= v;
+                }
+            }
+        }
+        __syncthreads();
+        FP(4);
     }
     for (int j = tid; j < m; j += nt) {
         if (j < k) y[idx[j]] = tl[j] / dv[j];
         else uvec[F.u_off + j - k] = tl[j];
     }
+    FP(5);
 }
 
 // backward:  x_j = W_j' ( y_j - D_j^{-1} W_j G_j ),  G[q] = sum over solved rows r of A[r, q] x[r]
@@ -1601,42 +1677,43 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __res
     const int wa = tid % NB, wb = tid / NB;
     const int last = ((k - 1) / NB) * NB;
     double wnext = (wa < wb && last + wb < k) ? Fm[(last + wa) + (int64_t)(last + wb) * m] : 0.0;
+    double dnext = (tid < NB && last + tid < k) ? dv[last + tid] : 1.0;
     __syncthreads();
     for (int j0 = last; j0 >= 0; j0 -= NB) {
         const int nb = min(NB, k - j0);
         Wl[wb * (NB + 1) + wa] = (wa < wb) ? wnext : (wa == wb ? 1.0 : 0.0);
-        if (tid < NB) dl[tid] = (tid < nb) ? dv[j0 + tid] : 1.0;
+        if (tid < NB) dl[tid] = dnext;
         __syncthreads();
         if (j0 >= NB) {
-            const int jn = j0 - NB;
+            const int jn = j0 - NB;          // a full block
             wnext = (wa < wb) ? Fm[(jn + wa) + (int64_t)(jn + wb) * m] : 0.0;
+            dnext = (tid < NB) ? dv[jn + tid] : 1.0;
         }
-        if (tid < 64) {
-            const int q = tid & 31;
-            double h = 0.0;
-            if (q < nb)
-                for (int c = 0; c <= q; ++c) h += Wl[q * (NB + 1) + c] * gl[j0 + c];
-            const double z = (q < nb) ? tl[j0 + q] - h / dl[q] : 0.0;
-            zq[q] = z;
-            wave_sync();
-            double xv = 0.0;
-            if (q < nb)
-                for (int qq = q; qq < nb; ++qq) xv += Wl[qq * (NB + 1) + q] * zq[qq];
-            wave_sync();
-            if (tid < nb) {
-                tl[j0 + tid] = xv;
-                x[idx[j0 + tid]] = xv;
+        {   // x_j = W' (y_j - D^{-1} W G_j) with all 1024 threads (see the forward sweep)
+            const int q = tid >> 5, c = tid & 31;
+            double ph = Wl[q * (NB + 1) + c] * (c < nb ? gl[j0 + c] : 0.0);
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) ph += __shfl_xor(ph, off, 32);
+            if (c == 0) zq[q] = (q < nb) ? tl[j0 + q] - ph / dl[q] : 0.0;
+            __syncthreads();
+            double px = Wl[c * (NB + 1) + q] * zq[c];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) px += __shfl_xor(px, off, 32);
+            if (c == 0 && q < nb) {
+                tl[j0 + q] = px;
+                x[idx[j0 + q]] = px;
             }
         }
         __syncthreads();
         for (int q = tid; q < j0; q += nt) {
             const double* Aq = Fm + (int64_t)q * m + j0;
             double v = 0.0;
-            if (nb == NB) {
+            for (int c0 = 0; c0 < nb; c0 += 8) {                // eight loads in flight (see the forward sweep)
+                double a[8];
 #pragma unroll
-                for (int c = 0; c < NB; ++c) v += Aq[c] * tl[j0 + c];
-            } else {
-                for (int c = 0; c < nb; ++c) v += Aq[c] * tl[j0 + c];
+                for (int u = 0; u < 8; ++u) a[u] = Aq[min(c0 + u, nb - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += a[u] * (c0 + u < nb ? tl[j0 + c0 + u] : 0.0);
             }
             gl[q] += v;
         }
@@ -1659,8 +1736,36 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     std::vector<FrontDev> fd(nf);
     for (int32_t i = 0; i < nf; ++i) {
         const Front& f = plan.fronts[i];
-        fd[i] = FrontDev{f.k, f.m, f.nchild, f.a_cnt, f.F_off, f.idx_off, f.u_off, f.child_off, f.rel_off, f.a_off, f.acol_off};
+        fd[i] = FrontDev{f.k, f.m, f.nchild, f.a_cnt, f.F_off, f.idx_off, f.u_off, f.child_off, f.rel_off, f.a_off, f.acol_off, -1};
     }
+    // update-vector gather lists of the large fronts (forward solve): for every local index the entries of
+    // the children's update vectors that land on it, in child order (the summation order of the extend-add)
+    std::vector<int64_t> ug_ptr, ug_src;
+    for (int32_t i = 0; i < nf; ++i) {
+        const Front& f = plan.fronts[i];
+        if (f.m <= 128) continue;
+        fd[i].ug_off = (int64_t)ug_ptr.size();
+        std::vector<int32_t> cnt((size_t)f.m + 1, 0);
+        for (int32_t c = 0; c < f.nchild; ++c) {
+            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
+            for (int32_t j = 0; j < ch.m - ch.k; ++j) cnt[plan.rel[ch.rel_off + j] + 1]++;
+        }
+        const int64_t base = (int64_t)ug_src.size();
+        std::vector<int64_t> pos((size_t)f.m + 1);
+        pos[0] = base;
+        for (int32_t j = 0; j < f.m; ++j) pos[j + 1] = pos[j] + cnt[j + 1];
+        ug_ptr.insert(ug_ptr.end(), pos.begin(), pos.end());
+        ug_src.resize((size_t)pos[f.m]);
+        std::vector<int64_t> fill(pos.begin(), pos.end() - 1);
+        for (int32_t c = 0; c < f.nchild; ++c) {
+            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
+            for (int32_t j = 0; j < ch.m - ch.k; ++j) ug_src[(size_t)fill[plan.rel[ch.rel_off + j]]++] = ch.u_off + j;
+        }
+    }
+    if (ug_ptr.empty()) ug_ptr.push_back(0);
+    if (ug_src.empty()) ug_src.push_back(0);
+    d_ug_ptr.upload(ug_ptr, st);
+    d_ug_src.upload(ug_src, st);
     d_fronts.upload(fd, st);
     d_front_idx.upload(plan.front_idx, st);
     d_children.upload(plan.children, st);
@@ -1693,7 +1798,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     bool inv_ok = true;
     if (const char* e = getenv("MGBHIP_OLD_BIG"); e && e[0] == '1') inv_ok = false;
     if (inv_ok) {
-        const int lds = (2 * BIG_INV_MAX_M + NB * (NB + 1) + 4 * NB + 8) * (int)sizeof(double);
+        const int lds = (2 * BIG_INV_MAX_M + NB * (NB + 1) + 4 * NB + 8 + BIGI_THREADS) * (int)sizeof(double);
         if (hipFuncSetAttribute((const void*)mf_fwd_inv, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
             hipFuncSetAttribute((const void*)mf_bwd_inv, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             (void)hipGetLastError();
@@ -1810,12 +1915,17 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
                 hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,
                                    d_a_src.p, d_a_dst.p, d_a_colptr.p, d_values, d_arena.p);
+                // many fronts: factor block 0 once per front up front instead of inside every tile of step 0
+                const bool pre_diag = L.count >= 24;
+                if (pre_diag)
+                    hipLaunchKernelGGL(mf_big_diag0, dim3(L.count), dim3(256), 0, st, d_fronts.p, L.first, d_arena.p, d_dscr.p,
+                                       d_status.p);
                 for (int j0 = 0; j0 < L.max_k; j0 += NB) {
                     const int rem = L.max_m - j0;
                     const int T = std::max(0, (rem - 1 + ST - 1) / ST);
                     const dim3 gs(T * (T + 1) / 2 + 1, L.count);         // trailing tiles + the look-ahead workgroup
                     hipLaunchKernelGGL(mf_big_step, gs, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p, d_dscr.p,
-                                       d_dvec.p, d_status.p, j0 == 0 ? 1 : 0);
+                                       d_dvec.p, d_status.p, (j0 == 0 && !pre_diag) ? 1 : 0);
                 }
             } else {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
@@ -1861,9 +1971,9 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
                                    st, d_fronts.p, L.first, L.count, ts, d_front_idx.p, d_children.p, d_rel.p,
                                    d_arena.p, d_b, d_y.p, d_uvec.p);
             } else if (L.inv) {
-                const size_t lds = (size_t)(((L.max_m + 1) & ~1) + NB * (NB + 1) + 2 * NB) * sizeof(double);
+                const size_t lds = (size_t)(((L.max_m + 1) & ~1) + NB * (NB + 1) + 2 * NB + BIGI_THREADS) * sizeof(double);
                 hipLaunchKernelGGL(mf_fwd_inv, dim3(L.count), dim3(BIGI_THREADS), lds, st, d_fronts.p, L.first,
-                                   d_front_idx.p, d_children.p, d_rel.p, d_arena.p, d_dvec.p, d_b, d_y.p, d_uvec.p);
+                                   d_front_idx.p, d_ug_ptr.p, d_ug_src.p, d_arena.p, d_dvec.p, d_b, d_y.p, d_uvec.p);
             } else if (L.max_m <= BIG1_MAX_M) {
                 const size_t lds = (size_t)(((L.max_m + 1) & ~1) + NB * (NB + 1)) * sizeof(double);
                 hipLaunchKernelGGL(mf_fwd_big1, dim3(L.count), dim3(BIG1_THREADS), lds, st, d_fronts.p, L.first,

@@ -13,6 +13,7 @@ namespace mgbhip {
 struct FrontDev {
     int32_t k, m, nchild, a_cnt;
     int64_t F_off, idx_off, u_off, child_off, rel_off, a_off, acol_off;
+    int64_t ug_off;        // large fronts: offset of the update-vector gather list (m + 1 pointers), -1 otherwise
 };
 
 struct MfLaunch {          // one kernel launch: a contiguous range of fronts of one size class
@@ -43,6 +44,7 @@ class MfSolver {
    private:
     DevBuf<FrontDev> d_fronts;
     DevBuf<int32_t> d_front_idx, d_children, d_rel, d_a_src, d_a_dst, d_a_colptr;
+    DevBuf<int64_t> d_ug_ptr, d_ug_src;   // per large front: for every local index the children's update-vector entries, in child order
     DevBuf<double> d_arena, d_uvec, d_y, d_tbig, d_tsol, d_dscr, d_dvec;
     DevBuf<int32_t> d_status;
     std::vector<std::vector<MfLaunch>> level_launches;   // per level, leaves first (factorization: one per LDS class)

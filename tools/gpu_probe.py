@@ -19,3 +19,4 @@ print("tile0 entry - LA entry (us):", (v[16] - v[0]) * 0.01)
 print("LDLT shader cycles:", v[33] - v[32], "-> clock GHz ~", (v[33] - v[32]) / ((v[5] - v[4]) * 10.0))
 D.close()
 print("LDLT clock at columns 0,8,16,24 (cycles since col 0):", [int(v[40+i]-v[40]) for i in range(4)], "end:", int(v[33]-v[40]), "start->col0:", int(v[40]-v[32]))
+print("fwd_inv level-6 front (us since entry): after init gather, W ready, wave0 done, rows done, end:", [round((v[48+i]-v[48])*0.01,2) for i in range(1,6)])
