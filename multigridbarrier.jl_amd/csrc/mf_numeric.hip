@@ -1533,7 +1533,7 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __res
                                                            double* __restrict__ uvec) {
     extern __shared__ double sh[];
 #ifdef MGB_STEP_PROBE
-#define FP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && gridDim.x > 150) g_probe[48 + i] = wall_clock64(); } while (0)
+#define FP(i) do { if (threadIdx.x == 0 && gridDim.x > 150) { const long long _t = wall_clock64(); if (blockIdx.x == 0) g_probe[48 + i] = _t; if (i == 0) atomicMin((unsigned long long*)&g_probe[56], (unsigned long long)_t); if (i == 5) { atomicMax((unsigned long long*)&g_probe[57], (unsigned long long)_t); atomicAdd((unsigned long long*)&g_probe[58], (unsigned long long)(_t - g_probe[56])); } } } while (0)
 #else
 #define FP(i) do { } while (0)
 #endif
@@ -1553,7 +1553,14 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __res
         const int64_t* up = ug_ptr + F.ug_off;
         for (int j = tid; j < m; j += nt) {
             double v = (j < k) ? b[idx[j]] : 0.0;
-            for (int64_t e = up[j]; e < up[j + 1]; ++e) v += uvec[ug_src[e]];
+            const int64_t e1 = up[j + 1];
+            for (int64_t e = up[j]; e < e1; e += 4) {           // four contributions in flight, added in list order
+                double a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = (e + u < e1) ? uvec[ug_src[e + u]] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v += a[u];
+            }
             tl[j] = v;
         }
     }
@@ -2032,7 +2039,13 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
 }
 
 #ifdef MGB_STEP_PROBE
-void mf_debug_probe(long long* out64) { (void)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_probe), 64 * sizeof(long long)); }
+void mf_debug_probe(long long* out64) {
+    (void)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_probe), 64 * sizeof(long long));
+    long long init[64];
+    for (int i = 0; i < 64; ++i) init[i] = 0;
+    init[56] = 0x7fffffffffffffffll;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe), init, sizeof(init));
+}
 #endif
 
 void MfSolver::status_async(int32_t* h_dst, hipStream_t st) const {

@@ -8,8 +8,11 @@ D = DeviceMGBProblem(prob); P = D.main
 J = len(P.level_sizes) - 1
 z0 = np.ascontiguousarray(prob.g.T).reshape(-1); c = 0.1 * prob.f; s = np.zeros(P.level_sizes[J])
 g = P.f1(J, s, c, z0); P.f2(J, s, c, z0, want_matrix=False)
-for _ in range(3):
-    P.solve(J, g)
+P.solve(J, g)
+probe0 = (C.c_longlong * 64)()
+P.lib.mgbhip_debug_probe(probe0)   # resets the min/max slots
+P.solve(J, g)
+
 out = (C.c_longlong * 64)()
 P.lib.mgbhip_debug_probe(out)
 v = np.array(out[:])
@@ -20,3 +23,4 @@ print("LDLT shader cycles:", v[33] - v[32], "-> clock GHz ~", (v[33] - v[32]) / 
 D.close()
 print("LDLT clock at columns 0,8,16,24 (cycles since col 0):", [int(v[40+i]-v[40]) for i in range(4)], "end:", int(v[33]-v[40]), "start->col0:", int(v[40]-v[32]))
 print("fwd_inv level-6 front (us since entry): after init gather, W ready, wave0 done, rows done, end:", [round((v[48+i]-v[48])*0.01,2) for i in range(1,6)])
+print("fwd_inv level-6 kernel: first start -> last end (us):", (v[57]-v[56])*0.01)
