@@ -194,15 +194,27 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         ++k;
         C.F2(P->d_x.p);
         auto t0 = std::chrono::steady_clock::now();
-        P->factor(C.level);
-        P->trisolve(C.level, P->d_g.p, P->d_nv.p);
-        // pivot flag, direction statistics and lambda^2 = <g, n> in one round trip
-        launch_vec_stats(P->d_nv.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st);
-        launch_dot(P->d_g.p, P->d_nv.p, C.m, P->d_scratch.p, P->d_scal.p + 4, st);
-        MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-        L.solver.status_async(P->pin.i + 1, st);
-        MGB_HIP_CHECK(hipStreamSynchronize(st));
-        const int fstatus = MfSolver::status_from(P->pin.i[1]);
+        int fstatus = MGBHIP_OK;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            P->factor(C.level);
+            P->trisolve(C.level, P->d_g.p, P->d_nv.p);
+            // pivot flag, direction statistics and lambda^2 = <g, n> in one round trip
+            launch_vec_stats(P->d_nv.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st);
+            launch_dot(P->d_g.p, P->d_nv.p, C.m, P->d_scratch.p, P->d_scal.p + 4, st);
+            MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            L.solver.status_async(P->pin.i + 1, st);
+            MGB_HIP_CHECK(hipStreamSynchronize(st));
+            fstatus = MfSolver::status_from(P->pin.i[1]);
+            // The fast large-front kernels apply inverted 32 x 32 diagonal blocks; near the edge of singularity
+            // that loses digits a substitution keeps.  A failed pivot, a non-finite direction or lambda^2 <= 0
+            // is re-done once with the substitution kernels before the reference's own tests see it.
+            const bool suspicious = fstatus != MGBHIP_OK || P->pin.d[3] != 0.0 || !std::isfinite(P->pin.d[2]) || !(P->pin.d[4] > 0);
+            if (!suspicious || attempt == 1 || !L.solver.has_inverse_path() || L.solver.robust) break;
+            DBG("newton[lev %d] k=%d: direction rejected (status %d, lambda^2=%.3e): refactoring with the substitution kernels\n",
+                C.level, k, fstatus, P->pin.d[4]);
+            L.solver.robust = true;
+            L.factored = false;
+        }
         P->cnt.solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (fstatus != MGBHIP_OK) {
             DBG("newton[lev %d] k=%d: Cholesky met a non-positive pivot (y=%.17g |g|=%.6e)\n", C.level, k, y, gnorm);
@@ -236,6 +248,7 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         ymin = std::fmin(ymin, y);
         incmin = std::fmin(inc, incmin);
     }
+    L.solver.robust = false;          // the next Newton solve starts on the fast kernels again
     DBG("newton[lev %d] done k=%d converged=%d y=%.17g\n", C.level, k, (int)converged, y);
     R.k = k;
     R.converged = converged;

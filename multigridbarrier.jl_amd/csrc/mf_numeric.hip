@@ -1813,6 +1813,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
         }
     }
     static const int32_t classes[] = {16, 32, 48, 64, 88, 128};
+    uses_inv = false;
     level_launches.clear();
     const int32_t nlev = (int32_t)plan.level_ptr.size() - 1;
     level_launches.resize(nlev);
@@ -1837,7 +1838,10 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             L.max_m = plan.fronts[j - 1].m;
             L.max_k = 0;
             L.tiny = (l == 0 && cls == 16);     // leaves with m <= 16: 16 lanes per front
-            L.inv = (cls == 0 && L.max_m <= BIG_INV_MAX_M && inv_ok);
+            // inverse-based path: large systems only (small coarse systems cost nothing either way and are the ones
+            // the barrier method drives to the edge of singularity, where substitution is the safer arithmetic)
+            L.inv = (cls == 0 && L.max_m <= BIG_INV_MAX_M && inv_ok && plan.n >= 4096);
+            uses_inv = uses_inv || L.inv;
             for (int32_t q = i; q < j; ++q) L.max_k = std::max(L.max_k, plan.fronts[q].k);
             level_launches[l].push_back(L);
             i = j;
@@ -1890,6 +1894,7 @@ static StageTimers* timers_or_dummy(StageTimers* t, bool on) { return (t && on) 
 void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timers) {
     MGB_REQUIRE(analyzed, "MfSolver::factor before analyze");
     if (timers) timers->begin("factor");
+    factored_inv = !robust;
     d_status.zero(st);
     static const bool lvl_timing = [] { const char* e = getenv("MGBHIP_LEVEL_TIMING"); return e && e[0] == '1'; }();
     int lvno = -1;
@@ -1918,7 +1923,7 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 else
                     hipLaunchKernelGGL(mf_factor_small<32>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
                                        d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
-            } else if (L.inv) {
+            } else if (L.inv && !robust) {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
                 hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,
                                    d_a_src.p, d_a_dst.p, d_a_colptr.p, d_values, d_arena.p);
@@ -1977,7 +1982,7 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
                 hipLaunchKernelGGL(mf_forward_small, dim3((L.count + 3) / 4), dim3(256), (size_t)4 * ts * sizeof(double),
                                    st, d_fronts.p, L.first, L.count, ts, d_front_idx.p, d_children.p, d_rel.p,
                                    d_arena.p, d_b, d_y.p, d_uvec.p);
-            } else if (L.inv) {
+            } else if (L.inv && factored_inv) {
                 const size_t lds = (size_t)(((L.max_m + 1) & ~1) + NB * (NB + 1) + 2 * NB + BIGI_THREADS) * sizeof(double);
                 hipLaunchKernelGGL(mf_fwd_inv, dim3(L.count), dim3(BIGI_THREADS), lds, st, d_fronts.p, L.first,
                                    d_front_idx.p, d_ug_ptr.p, d_ug_src.p, d_arena.p, d_dvec.p, d_b, d_y.p, d_uvec.p);
@@ -2013,7 +2018,7 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
             } else if (L.cls) {
                 hipLaunchKernelGGL(mf_backward_small, dim3((L.count + 3) / 4), dim3(256), 0, st, d_fronts.p, L.first,
                                    L.count, d_front_idx.p, d_arena.p, d_y.p, d_x);
-            } else if (L.inv) {
+            } else if (L.inv && factored_inv) {
                 const size_t lds = (size_t)(((L.max_m + 1) & ~1) + ((L.max_k + 1) & ~1) + NB * (NB + 1) + 2 * NB) * sizeof(double);
                 hipLaunchKernelGGL(mf_bwd_inv, dim3(L.count), dim3(BIGI_THREADS), lds, st, d_fronts.p, L.first,
                                    d_front_idx.p, d_arena.p, d_dvec.p, d_y.p, d_x);

@@ -40,6 +40,13 @@ class MfSolver {
     void status_async(int32_t* h_dst, hipStream_t st) const;
     static int status_from(int32_t flag) { return flag ? MGBHIP_ERR_NOT_SPD : MGBHIP_OK; }
     bool analyzed = false;
+    // The inverse-based large-front kernels apply W = L_jj^{-1} where a substitution would run: as fast as a
+    // GEMM, but only forward stable in cond(L_jj).  `robust` (set by the Newton loop when a direction fails its
+    // sanity checks) makes factor() / solve() take the substitution-based kernels for every front instead.
+    bool robust = false;
+    bool has_inverse_path() const { return uses_inv; }
+    // which representation the current factors are in (solve() must match the last factor())
+    bool factored_inv = false;
 
    private:
     DevBuf<FrontDev> d_fronts;
@@ -50,6 +57,7 @@ class MfSolver {
     std::vector<std::vector<MfLaunch>> level_launches;   // per level, leaves first (factorization: one per LDS class)
     std::vector<std::vector<MfLaunch>> level_solves;     // triangular solves: all LDS-class fronts of a level in one launch
     int32_t lds_cap = 88;           // largest m factored out of LDS
+    bool uses_inv = false;
 };
 
 }  // namespace mgbhip

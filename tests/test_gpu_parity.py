@@ -610,3 +610,30 @@ def test_reference_cuda_extension_cases_device_vs_cpu(name):
     ref = O.mgb_solve(prob)
     assert np.abs(sol.z - ref["z"]).max() < 1e-8                        # the reference's criterion (test/test_cuda.jl:51)
     assert "mgb_solve: device = HIPDevice" in sol.log
+
+
+def test_config4_default_start_phase1_full_size():
+    """BASELINE configs[3] at full size from the DEFAULT (infeasible) start: fem3d() Q1 p = 4, L = 6 -- phase I with
+    box escalation, `_matched_t` hand-off, main ramp -- checked by invariants (no oracle run at 262 144 nodes):
+    strictly feasible result, Dirichlet data exact, and a second solve on the resident image is bitwise identical
+    with the same iteration counts.  Hierarchy: max_coarse=300 (the reference default ladder stalls in phase I's
+    initial centring here, like the p = 1.5 case pinned above)."""
+    from mgb_amd.solve import mgb_driver
+    prob = m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 6), prolongator=m.amg_ruge_stuben(max_coarse=300)), p=4.0)
+    n = prob.M[0].w.size
+    assert n == 262144
+    sol = m.mgb_solve(prob, keep_device=True)
+    try:
+        assert sol.SOL_feasibility is not None                       # the default start is infeasible (s^(2/p) = 10 < |grad g|^2 near corners)
+        F = sol.device.main.node_barrier(stacked(sol.z))
+        assert np.all(np.isfinite(F))                                # strictly inside the cone at every node
+        assert sol.device.main.node_slack(stacked(sol.z)).max() < 0
+        bnd = np.array([v + e * 8 for (v, e) in m.find_boundary(prob.geometry)])
+        assert np.abs(sol.z[bnd, 0] - prob.g[bnd, 0]).max() < 1e-12   # Dirichlet data preserved exactly
+        again = mgb_driver(sol.device)
+        assert np.array_equal(again["z"], sol.z)
+        assert np.array_equal(again["SOL_main"]["its"], sol.SOL_main["its"])
+        assert np.array_equal(again["SOL_feasibility"]["its"], sol.SOL_feasibility["its"])
+        assert sol.SOL_main["ts"][-1] >= 1.0 / np.sqrt(np.finfo(float).eps)
+    finally:
+        sol.device.close()
