@@ -1840,7 +1840,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             L.tiny = (l == 0 && cls == 16);     // leaves with m <= 16: 16 lanes per front
             // inverse-based path: large systems only (small coarse systems cost nothing either way and are the ones
             // the barrier method drives to the edge of singularity, where substitution is the safer arithmetic)
-            L.inv = (cls == 0 && L.max_m <= BIG_INV_MAX_M && inv_ok && plan.n >= 4096);
+            L.inv = (cls == 0 && L.max_m <= BIG_INV_MAX_M && inv_ok && plan.n >= 1024);
             uses_inv = uses_inv || L.inv;
             for (int32_t q = i; q < j; ++q) L.max_k = std::max(L.max_k, plan.fronts[q].k);
             level_launches[l].push_back(L);
