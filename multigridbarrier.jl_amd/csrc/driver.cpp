@@ -83,8 +83,7 @@ struct NewtonCtx {
 bool trial_values(NewtonCtx& C, double& ynext, double& gnorm_next, int32_t* moved = nullptr) {
     mgbhip_problem* P = C.P;
     hipStream_t st = P->stream();
-    P->eval_f0_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c);
-    C.F1(P->d_xn.p, P->d_gn.p);
+    P->eval_f01_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c, P->d_gn.p);
     launch_vec_stats(P->d_gn.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st);
     MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d, P->d_scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     MGB_HIP_CHECK(hipMemcpyAsync(P->pin.i, P->d_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));

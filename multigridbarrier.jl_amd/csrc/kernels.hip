@@ -131,6 +131,55 @@ __global__ __launch_bounds__(256) void elem_kernel(const ElemParams P, const int
         if (active) P.out_F[node] = cone_slack<NY>(P.cone, node, n, y);
         return;
     }
+    if (MODE == MODE_F01) {
+        // One line-search trial (src/newton.jl:35-50 evaluates F0 then F1 at the same point): the operator
+        // blocks, z and c are streamed once instead of twice.
+        double val = 0.0;
+        if (active) {
+            double F0v;
+            cone_eval<NY, 0>(P.cone, node, n, y, F0v, g, H);
+            cone_eval<NY, 1>(P.cone, node, n, y, F, g, H);
+            const double wv = P.w[node];
+            const double bwv = P.bw ? P.bw[node] : 0.0;
+            const double bar = P.bw ? ((bwv == 0.0) ? 0.0 : bwv * F0v) : P.invn * F0v;
+            double lin = 0.0;
+#pragma unroll
+            for (int k = 0; k < NY; ++k) {
+                const double ck = P.c[node + n * k];
+                lin += ck * y[k];
+                const double sc = P.bw ? ((bwv == 0.0) ? 0.0 : bwv * g[k]) : P.invn * g[k];
+                YL[(el * NY + k) * G + r] = sc + wv * ck;
+            }
+            val = bar + wv * lin;
+        }
+        __syncthreads();
+        if (active) {
+            const int i = r;
+            for (int a = 0; a < nu; ++a) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NY; ++k) {
+                    if (P.D_state[k] != a) continue;
+                    const double* Yk = YL + (el * NY + k) * G;
+                    if (P.D_stage[k] == -1) {
+                        acc += Yk[i];
+                    } else {
+                        for (int rr = 0; rr < p; ++rr) acc += OP(k, rr, i) * Yk[rr];
+                    }
+                }
+                P.out_ret[(int64_t)a * n + node] = acc;
+            }
+        }
+        __syncthreads();            // zl / opL / YL no longer needed: reuse LDS for the reduction
+        sh[tid] = val;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) sh[tid] += sh[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) P.out_partial[blockIdx.x] = sh[0];
+        return;
+    }
     if (MODE == MODE_F1) {
         // Y = scale(grad F) + w .* c   (src/convex.jl:170-173), then sum_k D_k' Y_k per element
         if (active) {
@@ -885,6 +934,7 @@ void launch_elem_ny(const ElemParams& P, int mode, int lgG, dim3 grid, size_t ld
         case MODE_F2: hipLaunchKernelGGL((elem_kernel<NY, MODE_F2>), grid, dim3(256), lds, st, P, lgG); break;
         case MODE_NODE_F: hipLaunchKernelGGL((elem_kernel<NY, MODE_NODE_F>), grid, dim3(256), lds, st, P, lgG); break;
         case MODE_NODE_SLACK: hipLaunchKernelGGL((elem_kernel<NY, MODE_NODE_SLACK>), grid, dim3(256), lds, st, P, lgG); break;
+        case MODE_F01: hipLaunchKernelGGL((elem_kernel<NY, MODE_F01>), grid, dim3(256), lds, st, P, lgG); break;
         default: throw InvalidArgument("launch_elem: bad mode");
     }
 }
@@ -897,6 +947,7 @@ void set_lds_attr() {
     (void)hipFuncSetAttribute((const void*)elem_kernel<NY, MODE_F2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)elem_kernel<NY, MODE_NODE_F>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)elem_kernel<NY, MODE_NODE_SLACK>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)elem_kernel<NY, MODE_F01>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipGetLastError();
 }
 
@@ -918,7 +969,7 @@ size_t elem_lds_bytes(const ElemParams& P, int mode) {
     const int G = elem_group(P.p);
     const int EPB = 256 / G;
     size_t d = 256 * (size_t)P.nu + (size_t)P.nstage * EPB * P.p * P.p;
-    if (mode == MODE_F1) d += 256 * (size_t)P.nD;
+    if (mode == MODE_F1 || mode == MODE_F01) d += 256 * (size_t)P.nD;
     if (mode == MODE_F2) d += 256 * (size_t)(P.nD * (P.nD + 1) / 2);
     if (d < 256) d = 256;
     return d * sizeof(double);

@@ -5,7 +5,8 @@
 
 namespace mgbhip {
 
-enum ElemMode { MODE_F0 = 0, MODE_F1 = 1, MODE_F2 = 2, MODE_NODE_F = 3, MODE_NODE_SLACK = 4 };
+enum ElemMode { MODE_F0 = 0, MODE_F1 = 1, MODE_F2 = 2, MODE_NODE_F = 3, MODE_NODE_SLACK = 4,
+                MODE_F01 = 5 };   // MODE_F01: value and gradient of one line-search trial in ONE pass over the operators
 
 struct ElemParams {
     int32_t p, nu, nD, nstage;

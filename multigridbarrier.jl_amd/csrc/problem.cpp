@@ -642,6 +642,31 @@ void mgbhip_problem::eval_f1(int level, const double* d_s, const double* d_zz, c
     cnt.f1++;
 }
 
+void mgbhip_problem::eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout) {
+    if (dense) {                    // the dense (spectral) path keeps its separate GEMV pipelines
+        eval_f0_launch(level, d_s, d_zz, d_cc);
+        eval_f1(level, d_s, d_zz, d_cc, d_gout);
+        return;
+    }
+    hipStream_t st = stream();
+    const Level& L = levels[level];
+    {
+        StageScope sc(ctx->timers, level + 1 == (int)levels.size() ? "f01" : "f01_coarse");
+        ElemParams E = base_params(level, d_s, d_zz, d_cc);
+        launch_elem(E, MODE_F01, st);
+        launch_reduce_partials(d_partials.p, elem_grid(p, N), d_scal.p, st);
+    }
+    {
+        StageScope sc(ctx->timers, "restrict");
+        if (L.T_chunks > 0)
+            launch_csr_matvec_chunked(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, d_tchunk.p, L.T_chunks, st);
+        else
+            launch_csr_matvec(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, false, L.T_long, st);
+    }
+    cnt.f0++;
+    cnt.f1++;
+}
+
 void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc) {
     ensure_plan(level);
     hipStream_t st = stream();

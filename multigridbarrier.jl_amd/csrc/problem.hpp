@@ -108,6 +108,8 @@ struct mgbhip_problem {
     // kernels only: the value lands in d_scal[0]; the caller batches the read-back
     void eval_f0_launch(int level, const double* d_s, const double* d_zz, const double* d_cc);
     void eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
+    // one line-search trial: f0 (value in d_scal[0]) and f1 (gradient in d_gout) from one sweep over the elements
+    void eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
     void eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc);
     // returns MGBHIP_OK or MGBHIP_ERR_NOT_SPD; x = H^{-1} g on the device
     void factor(int level);

@@ -14,7 +14,7 @@ D.main.reset_stage_timers(True)
 t0 = time.perf_counter(); S = mgb_driver(D); dt = time.perf_counter() - t0
 its = S["SOL_main"]["its"]
 print("its", int(its.sum()), "per level", its.sum(axis=1).tolist(), "wall %.3f s" % dt, "it/s %.1f" % (its.sum() / dt), "bitwise repeat", np.array_equal(z1, S["z"]))
-for st in ("f0", "f1", "f2", "assemble", "f0_coarse", "f1_coarse", "f2_coarse", "assemble_coarse", "restrict", "prolong", "factor", "trisolve"):
+for st in ("f0", "f1", "f01", "f2", "assemble", "f0_coarse", "f1_coarse", "f01_coarse", "f2_coarse", "assemble_coarse", "restrict", "prolong", "factor", "trisolve"):
     ms, cnt = D.main.stage_ms(st)
     if cnt:
         print(f"  {st:16s} n={cnt:5d} avg {1e3*ms/cnt:8.1f} us  total {ms:8.1f} ms")
