@@ -1,6 +1,7 @@
 // problem.cpp -- native_to_device for one (AMG, Convex) pair, the per-level R'HR assembly
 // plans, and the device-resident f0/f1/f2/solve primitives behind the C ABI.
 #include "problem.hpp"
+#include "plan_device.hpp"
 #include "dense.hpp"
 
 #include <algorithm>
@@ -377,7 +378,48 @@ void mgbhip_problem::ensure_plan(int level) {
             fprintf(stderr, "[mgbhip] assembly plan level %d: m=%lld selection=%d cmax=%d slab=%lld doubles, accumulators=%lld -> %s\n", level,
                     (long long)m, (int)selection, cmax_all, (long long)slab_est, (long long)(waves * mt), L.acc ? "LDS accumulate" : "slab + gather");
     }
-    if (L.acc) {
+    // Pattern + contribution lists: one stable radix sort on the device (plan_device.hip) unless the pair
+    // count is out of its range or MGBHIP_HOST_PLAN=1 asks for the host builder below (kept as the
+    // cross-check: tests compare the two bit for bit).
+    std::vector<int64_t> eoff;
+    if (!selection && !L.acc) {
+        eoff.assign((size_t)NE + 1, 0);
+        for (int64_t e = 0; e < NE; ++e) {
+            const int64_t ct = ecol_ptr[(e + 1) * nu] - ecol_ptr[e * nu];
+            eoff[e + 1] = eoff[e] + ct * ct;
+        }
+        MGB_REQUIRE(eoff[NE] < (int64_t)INT32_MAX, "projected slab exceeds 32-bit indexing");
+        L.slab_doubles = eoff[NE];
+    }
+    bool device_plan = false;
+    if (!L.acc && m > 0) {
+        static const bool host_plan = [] { const char* e = getenv("MGBHIP_HOST_PLAN"); return e && e[0] == '1'; }();
+        PlanDeviceIn in;
+        std::memset(&in, 0, sizeof(in));
+        in.selection = selection; in.NE = NE; in.n = nn; in.m = m; in.p = pp; in.nu = nu;
+        in.slab_doubles = L.slab_doubles;
+        in.diag_mask_sel = diag_mask_sel;
+        for (int a = 0; a < nu; ++a) if (state_id[a]) in.state_id_mask |= 1u << a;
+        hel_layout(nu, NE, pp, diag_mask_sel, in.sel_off);
+        if (!host_plan && plan_device_pairs(in) <= PLAN_DEVICE_MAX_PAIRS) {
+            if (selection) {
+                in.Rptr = L.Rptr.p; in.Rcol = L.Rcol.p;
+            } else {
+                std::vector<int32_t> eoff32(eoff.begin(), eoff.end());
+                L.eoff.upload(eoff32, st);
+                L.ecol_ptr.upload(ecol_ptr, st);
+                L.ecols.upload(ecols.data(), ecols.size(), st);
+                if (ecols.empty()) L.ecols.alloc(1);
+                MGB_HIP_CHECK(hipStreamSynchronize(st));     // eoff32 is a local
+                in.ecol_ptr = L.ecol_ptr.p; in.ecols = L.ecols.p; in.eoff = L.eoff.p;
+            }
+            build_plan_device(in, L, st);
+            device_plan = true;
+        }
+    }
+    if (device_plan) {
+        // pattern, lists and their host copies are in place
+    } else if (L.acc) {
         L.hHcol.resize((size_t)(m * m));
         for (int64_t i = 0; i <= m; ++i) L.hHptr[i] = (int32_t)(i * m);
         for (int64_t i = 0; i < m; ++i)
@@ -444,9 +486,11 @@ void mgbhip_problem::ensure_plan(int level) {
             L.hHptr[i + 1] = (int32_t)L.hHcol.size();
         }
     }
-    L.nnz = (int64_t)L.hHcol.size();
-    L.Hptr.upload(L.hHptr, st);
-    L.Hcol.upload(L.hHcol, st);
+    if (!device_plan) {
+        L.nnz = (int64_t)L.hHcol.size();
+        L.Hptr.upload(L.hHptr, st);
+        L.Hcol.upload(L.hHcol, st);
+    }
     L.Hval.alloc((size_t)L.nnz);
     L.selection = selection;
     const int NB = hel_blocks(nu);
@@ -458,16 +502,6 @@ void mgbhip_problem::ensure_plan(int level) {
         const int32_t* hi = L.hHcol.data() + L.hHptr[row + 1];
         return (int32_t)(std::lower_bound(lo, hi, col) - L.hHcol.data());
     };
-    std::vector<int64_t> eoff;
-    if (!selection && !L.acc) {
-        eoff.assign((size_t)NE + 1, 0);
-        for (int64_t e = 0; e < NE; ++e) {
-            const int64_t ct = ecol_ptr[(e + 1) * nu] - ecol_ptr[e * nu];
-            eoff[e + 1] = eoff[e] + ct * ct;
-        }
-        MGB_REQUIRE(eoff[NE] < (int64_t)INT32_MAX, "projected slab exceeds 32-bit indexing");
-        L.slab_doubles = eoff[NE];
-    }
     int64_t sel_off[MGBHIP_MAX_NU * (MGBHIP_MAX_NU + 1) / 2];
     hel_layout(nu, NE, pp, diag_mask_sel, sel_off);
     auto for_each = [&](auto&& emit) {
@@ -500,7 +534,7 @@ void mgbhip_problem::ensure_plan(int level) {
             }
         }
     };
-    if (!L.acc) {
+    if (!L.acc && !device_plan) {
         // one pass over the contributions: remember (position, source) pairs so that the binary
         // searches behind `find` run once, then bucket them by position
         std::vector<int32_t> ccount(L.nnz + 1, 0);
