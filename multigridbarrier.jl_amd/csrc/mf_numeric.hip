@@ -1108,10 +1108,11 @@ __global__ __launch_bounds__(BIG1_THREADS) void mf_bwd_big1(const FrontDev* __re
 //     S = A21 W_j'  (= L21 D),   L = S D^{-1},
 // instead of waiting for a separate triangular-solve kernel, and applies  C -= S L'  on the matrix
 // cores (v_mfma_f64_16x16x4_f64).  The panel itself is never written back: the arena keeps the
-// fully updated, UNSOLVED rows A21 and the triangular solves apply W_j / d_j on the fly
-// (L21 y = A21 (W_j' D^{-1} y)).  Home layout of a factored diagonal block: strictly UPPER triangle
-// = W_j transposed (entry (c, q), c < q, holds W_j[q][c]); the pivots d_j live in `dvec`; the lower
-// triangle keeps the unfactored block (sibling workgroups of step 0 still read it).
+// fully updated, UNSOLVED rows A21, and the triangular sweeps need one matrix per block,
+// M_j = W_j' D_j^{-1} W_j (the inverse of the updated diagonal block):  forward u_j = M_j t_j,
+// t_r -= A_rj u_j;  backward x_j = u_j - M_j G_j with G = A21' x_r.  Home layout of a factored
+// diagonal block: strictly UPPER triangle = off-diagonal of M_j, its diagonal lives in `dvec`;
+// the lower triangle keeps the unfactored block (sibling workgroups of step 0 still read it).
 constexpr int BIG_INV_MAX_M = 7000;     // work vectors of the single-workgroup solves stay in LDS
 constexpr int BIGI_THREADS = 1024;
 
@@ -1389,12 +1390,27 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
     PROBE(1);
     if (tid < NB) rdq[tid] = 1.0 / dq[tid];
     if (is_la) {
-        // home of block j: strictly upper triangle = W_j', pivots to dvec (nobody reads either during this step)
-        for (int i = tid; i < NB * NB; i += 256) {
-            const int q = i % NB, c = i / NB;          // entry (c, q), c < q
-            if (c < q && q < nb) W[(j0 + c) + (int64_t)(j0 + q) * m] = Wv[q][c];
+        // home of block j (nobody reads it during this step): M_j = W_j' D_j^{-1} W_j, the inverse of the updated
+        // diagonal block -- the triangular sweeps need nothing else of the block (mf_fwd_inv / mf_bwd_inv).
+        // Strictly upper triangle = off-diagonal of M_j, diagonal of M_j to dvec.  One 16 x 16 tile per wave on the
+        // matrix cores, straight from the accumulators (the tile above the diagonal is the mirror image: skipped).
+        {
+            const int rt = wave & 1, ct = wave >> 1;
+            if (ct <= rt) {
+                double4_t accm = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < NB / 4; ++kk) {
+                    const int kq = 4 * kk + fk;
+                    accm = __builtin_amdgcn_mfma_f64_16x16x4f64(kq < nb ? Wv[kq][16 * ct + fr16] / dq[kq] : 0.0, Wv[kq][16 * rt + fr16], accm, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * rt + fr16, col = 16 * ct + fk + 4 * r;
+                    if (row < nb && col < row) W[(j0 + col) + (int64_t)(j0 + row) * m] = accm[r];
+                    else if (row < nb && col == row) dvec[F.idx_off + j0 + row] = accm[r];
+                }
+            }
         }
-        if (tid < nb) dvec[F.idx_off + j0 + tid] = dq[tid];
         if (!look) return;
     }
     __syncthreads();
@@ -1522,7 +1538,8 @@ __global__ __launch_bounds__(256) void mf_big_diag0(const FrontDev* __restrict__
 }
 
 // ---- triangular solves on the inverse-based layout: one workgroup per front --------------------
-// forward:  y' = L^{-1} t by blocks:  y'_j = W_j t_j,  u = W_j' D_j^{-1} y'_j,  t[r] -= A[r, j] u  (r below)
+// forward, block j of a front:  u_j = M_j t_j,  t[r] -= A[r, j] u_j  (r below);  the stored intermediate is u
+// (M_j = A_jj^{-1} of the updated diagonal block = W_j' D_j^{-1} W_j, written home by mf_big_step)
 __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __restrict__ fr, int32_t first,
                                                            const int32_t* __restrict__ front_idx,
                                                            const int64_t* __restrict__ ug_ptr,
@@ -1542,10 +1559,9 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __res
     const int m = F.m, k = F.k;
     const int tid = threadIdx.x, nt = BIGI_THREADS;
     double* tl = sh;                               // [m]
-    double* Wl = sh + ((m + 1) & ~1);              // [NB][NB + 1]
-    double* dl = Wl + NB * (NB + 1);               // [NB]
-    double* uq = dl + NB;                          // [NB]
-    double* part = uq + NB;                        // [BIGI_THREADS] partial sums of the column-split row update
+    double* Ml = sh + ((m + 1) & ~1);              // [NB][NB + 1]: M_j, full symmetric
+    double* uq = Ml + NB * (NB + 1);               // [NB]
+    double* part = uq + 2 * NB;                    // [BIGI_THREADS] partial sums of the column-split row update
     const int32_t* idx = front_idx + F.idx_off;
     const double* Fm = arena + F.F_off;
     const double* dv = dvec + F.idx_off;
@@ -1564,53 +1580,67 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __res
             tl[j] = v;
         }
     }
-    const int wa = tid % NB, wb = tid / NB;          // W_j[q = wb][c = wa] sits at (j0 + wa, j0 + wb), wa < wb
-    double wnext = (wa < wb && wb < k) ? Fm[wa + (int64_t)wb * m] : 0.0;
-    double dnext = (tid < NB && tid < k) ? dv[tid] : 1.0;
+    const int wa = tid % NB, wb = tid / NB;          // M_j[wb][wa] = M_j[wa][wb] sits at (j0 + wa, j0 + wb), wa < wb
+    {
+        const double w0 = (wa < wb && wb < k) ? Fm[wa + (int64_t)wb * m] : 0.0;
+        if (wa < wb) { Ml[wb * (NB + 1) + wa] = w0; Ml[wa * (NB + 1) + wb] = w0; }
+        if (tid < NB) Ml[tid * (NB + 1) + tid] = (tid < k) ? dv[tid] : 0.0;
+    }
     __syncthreads();
     FP(1);
     for (int j0 = 0; j0 < k; j0 += NB) {
         const int nb = min(NB, k - j0), j1 = j0 + nb;
-        Wl[wb * (NB + 1) + wa] = (wa < wb) ? wnext : (wa == wb ? 1.0 : 0.0);      // zero upper part: fixed-length dots below
-        if (tid < NB) dl[tid] = dnext;
-        __syncthreads();
-        FP(2);
+        // next block's M and the first 16 panel entries of this thread's row update: neither depends on this
+        // block's product, so both are requested now and their latency runs under it
+        const int jn = j0 + NB;
+        const double wnext = (wa < wb && jn + wb < k) ? Fm[(jn + wa) + (int64_t)(jn + wb) * m] : 0.0;
+        const double dnext = (tid < NB && jn + tid < k) ? dv[jn + tid] : 0.0;
+        const int rows = m - j1;
+        int G = 1;
+        while (G < 8 && 2 * G * rows <= nt) G *= 2;
+        const int cgp = (G > 1 && rows > 0) ? tid / rows : 0, rr = (G > 1 && rows > 0) ? tid - cgp * rows : tid;
+        const bool mine = rows > 0 && (G == 1 ? tid < rows : cgp < G);
+        const int cstep = G == 1 ? 1 : G;                 // G == 1: columns 0..15 now, 16..31 later; G > 1: all 32 / G columns
+        double pa[16], pc[16];
         {
-            const int jn = j0 + NB;
-            wnext = (wa < wb && jn + wb < k) ? Fm[(jn + wa) + (int64_t)(jn + wb) * m] : 0.0;
-            dnext = (tid < NB && jn + tid < k) ? dv[jn + tid] : 1.0;
-        }
-        {   // the two 32 x 32 triangular products on all 1024 threads: thread (q, c) forms one term, a 32-lane
-            // butterfly sums the row -- two LDS round trips instead of two 32-step serial dots in one wave
-            const int q = tid >> 5, c = tid & 31;
-            double pr = Wl[q * (NB + 1) + c] * (c < nb ? tl[j0 + c] : 0.0);        // W is unit lower, zero above
+            const double* Ar = Fm + (j1 + rr) + (int64_t)j0 * m;
 #pragma unroll
-            for (int off = 16; off > 0; off >>= 1) pr += __shfl_xor(pr, off, 32);
-            __syncthreads();                                                      // every term has read t_j
-            if (c == 0 && q < nb) {
-                tl[j0 + q] = pr;                                                  // y'_j
-                uq[q] = pr / dl[q];
-            } else if (c == 0) {
-                uq[q] = 0.0;
+            for (int u = 0; u < 16; ++u) {
+                const int col = cgp + u * cstep;
+                pa[u] = (mine && col < NB) ? Ar[(int64_t)min(col, nb - 1) * m] : 0.0;
             }
-            __syncthreads();
-            double pu = Wl[c * (NB + 1) + q] * uq[c];                             // u[q] = sum_c W[c][q] (y'/d)[c]
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pc[u] = (mine && G == 1) ? Ar[(int64_t)min(16 + u, nb - 1) * m] : 0.0;
+        }
+        {   // u = M_j t_j on all 1024 threads: thread (q, c) forms one term, a 32-lane butterfly sums the row
+            const int q = tid >> 5, c = tid & 31;
+            double pu = Ml[q * (NB + 1) + c] * (c < nb ? tl[j0 + c] : 0.0);
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) pu += __shfl_xor(pu, off, 32);
-            __syncthreads();
             if (c == 0) uq[q] = (q < nb) ? pu : 0.0;
         }
         __syncthreads();
         FP(3);
+        // M_j is consumed: stage M_{j+1} (the barrier at the end of the step publishes it)
+        if (wa < wb) { Ml[wb * (NB + 1) + wa] = wnext; Ml[wa * (NB + 1) + wb] = wnext; }
+        if (tid < NB) {
+            Ml[tid * (NB + 1) + tid] = dnext;
+            if (tid < nb) tl[j0 + tid] = uq[tid];          // the intermediate the backward sweep starts from
+        }
         {   // rows below the block: t[r] -= A[r, j0 .. j1) u.  The panel is column-major, so a thread's 32 terms are
-            // 32 strided loads; they are issued eight at a time (a rolled loop waits one memory latency per term,
-            // a 32-way unroll spills at 1024 threads), and fronts with few rows split the columns over G thread
-            // groups so that all 1024 threads carry loads; the partial sums meet in LDS in a fixed order.
-            const int rows = m - j1;
-            int G = 1;
-            while (G < 8 && 2 * G * rows <= nt) G *= 2;
+            // 32 strided loads; they are issued in groups (a rolled loop waits one memory latency per term, a 32-way
+            // unroll spills at 1024 threads), and fronts with few rows split the columns over G thread groups so that
+            // all 1024 threads carry loads; the partial sums meet in LDS in a fixed order.
             if (rows > 0 && G == 1) {
-                for (int r = j1 + tid; r < m; r += nt) {
+                if (mine) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v += pa[u] * uq[u];                  // uq is zero beyond nb
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v += pc[u] * uq[16 + u];
+                    tl[j1 + tid] -= v;
+                }
+                for (int r = j1 + tid + nt; r < m; r += nt) {
                     const double* Ar = Fm + r + (int64_t)j0 * m;
                     double v = 0.0;
                     for (int c0 = 0; c0 < nb; c0 += 8) {
@@ -1618,20 +1648,17 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __res
 #pragma unroll
                         for (int u = 0; u < 8; ++u) a[u] = Ar[(int64_t)min(c0 + u, nb - 1) * m];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) v += a[u] * uq[c0 + u];          // uq is zero beyond nb
+                        for (int u = 0; u < 8; ++u) v += a[u] * uq[c0 + u];
                     }
                     tl[r] -= v;
                 }
             } else if (rows > 0) {
-                const int cgp = tid / rows, rr = tid - cgp * rows;
                 if (cgp < G) {
-                    const double* Ar = Fm + (j1 + rr) + (int64_t)j0 * m;
-                    double a[4], v = 0.0;
-                    for (int c0 = cgp; c0 < nb; c0 += 4 * G) {
+                    double v = 0.0;
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) a[u] = Ar[(int64_t)min(c0 + u * G, nb - 1) * m];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) v += a[u] * (c0 + u * G < nb ? uq[c0 + u * G] : 0.0);
+                    for (int u = 0; u < 16; ++u) {
+                        const int col = cgp + u * G;
+                        v += pa[u] * (col < nb ? uq[col] : 0.0);
                     }
                     part[cgp * rows + rr] = v;
                 }
@@ -1647,13 +1674,13 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __res
         FP(4);
     }
     for (int j = tid; j < m; j += nt) {
-        if (j < k) y[idx[j]] = tl[j] / dv[j];
+        if (j < k) y[idx[j]] = tl[j];
         else uvec[F.u_off + j - k] = tl[j];
     }
     FP(5);
 }
 
-// backward:  x_j = W_j' ( y_j - D_j^{-1} W_j G_j ),  G[q] = sum over solved rows r of A[r, q] x[r]
+// backward:  x_j = u_j - M_j G_j,  G[q] = sum over solved rows r of A[r, q] x[r]
 __global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __restrict__ fr, int32_t first,
                                                            const int32_t* __restrict__ front_idx,
                                                            const double* __restrict__ arena,
@@ -1664,55 +1691,69 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __res
     const int m = F.m, k = F.k;
     const int tid = threadIdx.x, nt = BIGI_THREADS;
     const int lane = tid & 63, wave = tid >> 6;
-    double* tl = sh;                               // [m]: y on the pivots (then x), x(boundary) below
+    double* tl = sh;                               // [m]: u on the pivots (then x), x(boundary) below
     double* gl = sh + ((m + 1) & ~1);              // [k]
-    double* Wl = gl + ((k + 1) & ~1);              // [NB][NB + 1]
-    double* dl = Wl + NB * (NB + 1);
-    double* zq = dl + NB;
+    double* Ml = gl + ((k + 1) & ~1);              // [NB][NB + 1]
+    double* zq = Ml + NB * (NB + 1);               // [NB]
     const int32_t* idx = front_idx + F.idx_off;
     const double* Fm = arena + F.F_off;
     const double* dv = dvec + F.idx_off;
     for (int j = tid; j < m; j += nt) tl[j] = (j < k) ? y[idx[j]] : x[idx[j]];
     __syncthreads();
-    for (int q = wave; q < k; q += nt / 64) {      // boundary rows: one wave per pivot column, coalesced along rows
-        const double* Aq = Fm + (int64_t)q * m;
-        double s = 0.0;
-        for (int r = k + lane; r < m; r += 64) s += Aq[r] * tl[r];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) gl[q] = s;
+    // boundary rows: one wave per pivot column, coalesced along rows; four columns per pass so that their loads
+    // and butterflies overlap (a wave owns up to k / 16 columns, each a dependent load -> reduce chain)
+    for (int q0 = 4 * wave; q0 < k; q0 += 4 * (nt / 64)) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int r = k + lane; r < m; r += 64) {
+            const double t = tl[r];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += Fm[(int64_t)min(q0 + u, k - 1) * m + r] * t;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            for (int off = 32; off > 0; off >>= 1) s[u] += __shfl_xor(s[u], off, 64);
+        if (lane < 4 && q0 + lane < k) gl[q0 + lane] = s[lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? 2 : 3))];
     }
     const int wa = tid % NB, wb = tid / NB;
     const int last = ((k - 1) / NB) * NB;
-    double wnext = (wa < wb && last + wb < k) ? Fm[(last + wa) + (int64_t)(last + wb) * m] : 0.0;
-    double dnext = (tid < NB && last + tid < k) ? dv[last + tid] : 1.0;
+    {
+        const double w0 = (wa < wb && last + wb < k) ? Fm[(last + wa) + (int64_t)(last + wb) * m] : 0.0;
+        if (wa < wb) { Ml[wb * (NB + 1) + wa] = w0; Ml[wa * (NB + 1) + wb] = w0; }
+        if (tid < NB) Ml[tid * (NB + 1) + tid] = (last + tid < k) ? dv[last + tid] : 0.0;
+    }
     __syncthreads();
     for (int j0 = last; j0 >= 0; j0 -= NB) {
         const int nb = min(NB, k - j0);
-        Wl[wb * (NB + 1) + wa] = (wa < wb) ? wnext : (wa == wb ? 1.0 : 0.0);
-        if (tid < NB) dl[tid] = dnext;
-        __syncthreads();
-        if (j0 >= NB) {
-            const int jn = j0 - NB;          // a full block
-            wnext = (wa < wb) ? Fm[(jn + wa) + (int64_t)(jn + wb) * m] : 0.0;
-            dnext = (tid < NB) ? dv[jn + tid] : 1.0;
+        const int jn = j0 - NB;              // the next block is a full one
+        const double wnext = (wa < wb && jn >= 0) ? Fm[(jn + wa) + (int64_t)(jn + wb) * m] : 0.0;
+        const double dnext = (tid < NB && jn >= 0) ? dv[jn + tid] : 0.0;
+        double pa[NB];                       // this thread's panel row, in flight under the block product
+        {
+            const double* Aq = Fm + (int64_t)tid * m + j0;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) pa[u] = (tid < j0) ? Aq[min(u, nb - 1)] : 0.0;
         }
-        {   // x_j = W' (y_j - D^{-1} W G_j) with all 1024 threads (see the forward sweep)
+        {   // x_j = u_j - M_j G_j with all 1024 threads (see the forward sweep)
             const int q = tid >> 5, c = tid & 31;
-            double ph = Wl[q * (NB + 1) + c] * (c < nb ? gl[j0 + c] : 0.0);
+            double ph = Ml[q * (NB + 1) + c] * (c < nb ? gl[j0 + c] : 0.0);
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) ph += __shfl_xor(ph, off, 32);
-            if (c == 0) zq[q] = (q < nb) ? tl[j0 + q] - ph / dl[q] : 0.0;
-            __syncthreads();
-            double px = Wl[c * (NB + 1) + q] * zq[c];
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) px += __shfl_xor(px, off, 32);
-            if (c == 0 && q < nb) {
-                tl[j0 + q] = px;
-                x[idx[j0 + q]] = px;
+            if (c == 0) {
+                const double xv = (q < nb) ? tl[j0 + q] - ph : 0.0;
+                zq[q] = xv;
+                if (q < nb) x[idx[j0 + q]] = xv;
             }
         }
         __syncthreads();
-        for (int q = tid; q < j0; q += nt) {
+        if (wa < wb) { Ml[wb * (NB + 1) + wa] = wnext; Ml[wa * (NB + 1) + wb] = wnext; }
+        if (tid < NB) Ml[tid * (NB + 1) + tid] = dnext;
+        if (tid < j0) {
+            double v = 0.0;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) v += pa[u] * zq[u];          // zq is zero beyond nb
+            gl[tid] += v;
+        }
+        for (int q = tid + nt; q < j0; q += nt) {
             const double* Aq = Fm + (int64_t)q * m + j0;
             double v = 0.0;
             for (int c0 = 0; c0 < nb; c0 += 8) {                // eight loads in flight (see the forward sweep)
@@ -1720,7 +1761,7 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __res
 #pragma unroll
                 for (int u = 0; u < 8; ++u) a[u] = Aq[min(c0 + u, nb - 1)];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v += a[u] * (c0 + u < nb ? tl[j0 + c0 + u] : 0.0);
+                for (int u = 0; u < 8; ++u) v += a[u] * zq[c0 + u];
             }
             gl[q] += v;
         }
