@@ -663,6 +663,44 @@ __global__ __launch_bounds__(256) void gather_assemble_wave_kernel(int64_t nnz, 
     if (lane == 0) Hval[q] = s;
 }
 
+// Very long lists (the coarsest levels: a handful of nonzeros, each summing every element): one wave per
+// (nonzero, chunk of the list), then one wave per nonzero over the chunk sums.  Fixed chunking and fixed
+// shuffle trees: the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void gather_assemble_chunk_kernel(int64_t nnz, int32_t ch, int32_t nchunk,
+                                                                    const int32_t* __restrict__ cptr,
+                                                                    const int32_t* __restrict__ cidx,
+                                                                    const double* __restrict__ slab,
+                                                                    double* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= nnz * nchunk) return;
+    const int64_t q = w / nchunk;
+    const int32_t c = (int32_t)(w - q * nchunk);
+    const int32_t beg = cptr[q] + c * ch, end = min(cptr[q + 1], beg + ch);
+    double s = 0.0;
+    for (int32_t t = beg + lane; t < end; t += 256) {      // four loads in flight per lane
+        const int32_t t1 = t + 64, t2 = t + 128, t3 = t + 192;
+        const double a0 = slab[cidx[t]];
+        const double a1 = t1 < end ? slab[cidx[t1]] : 0.0;
+        const double a2 = t2 < end ? slab[cidx[t2]] : 0.0;
+        const double a3 = t3 < end ? slab[cidx[t3]] : 0.0;
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) part[w] = s;
+}
+
+__global__ __launch_bounds__(256) void gather_assemble_chunk_reduce(int64_t nnz, int32_t nchunk, const double* __restrict__ part,
+                                                                    double* __restrict__ Hval) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nnz) return;
+    double s = 0.0;
+    for (int32_t c = lane; c < nchunk; c += 64) s += part[q * nchunk + c];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) Hval[q] = s;
+}
+
 // General (coarse) levels: one wave per element computes the projected block
 // [panel_0 .. panel_{nu-1}]' * Hel_e * [panel_0 .. panel_{nu-1}] in two steps per block pair
 // (tmp = Hel_ab * panel_b in LDS, then panel_a' * tmp) into the element's slab; the structural
@@ -1142,9 +1180,13 @@ void launch_fill(double value, double* y, int64_t len, hipStream_t st) {
 }
 
 void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,
-                            double* Hval, bool long_lists, hipStream_t st) {
+                            double* Hval, bool long_lists, hipStream_t st, int32_t chunk, int32_t nchunk, double* part) {
     if (nnz == 0) return;
-    if (long_lists)
+    if (long_lists && nchunk > 1) {
+        hipLaunchKernelGGL(gather_assemble_chunk_kernel, dim3((unsigned)((nnz * nchunk + 3) / 4)), dim3(256), 0, st, nnz, chunk,
+                           nchunk, cptr, cidx, slab, part);
+        hipLaunchKernelGGL(gather_assemble_chunk_reduce, dim3((unsigned)((nnz + 3) / 4)), dim3(256), 0, st, nnz, nchunk, part, Hval);
+    } else if (long_lists)
         hipLaunchKernelGGL(gather_assemble_wave_kernel, dim3((unsigned)((nnz + 3) / 4)), dim3(256), 0, st, nnz, cptr,
                            cidx, slab, Hval);
     else

@@ -79,7 +79,8 @@ void launch_fill(double value, double* y, int64_t len, hipStream_t st);       //
 
 // selection levels: H[q] = sum_{t in contributions(q)} slab[cidx[t]]
 void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,
-                            double* Hval, bool long_lists, hipStream_t st);
+                            double* Hval, bool long_lists, hipStream_t st, int32_t chunk = 0, int32_t nchunk = 0,
+                            double* part = nullptr);     // nchunk > 1: two-stage sums of very long lists
 
 // general (coarse) levels: slab_e = [panel_0 .. panel_{nu-1}]' * Hel_e * [panel_0 .. panel_{nu-1}]
 // (c_tot x c_tot, column-major, at eoff[e]); the structural nonzeros then gather from the slab.

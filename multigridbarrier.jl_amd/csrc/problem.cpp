@@ -560,6 +560,19 @@ void mgbhip_problem::ensure_plan(int level) {
         if (cidx.empty()) L.cidx.alloc(1);
         MGB_HIP_CHECK(hipStreamSynchronize(st));
     }
+    if (!L.acc && L.long_lists && L.nnz > 0) {
+        // very long lists (average > 2048 contributions): split every list into <= 64 fixed chunks
+        std::vector<int32_t> hc((size_t)L.nnz + 1);
+        L.cptr.download(hc.data(), hc.size(), st);
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
+        int64_t maxlen = 0;
+        for (int64_t q = 0; q < L.nnz; ++q) maxlen = std::max<int64_t>(maxlen, hc[q + 1] - hc[q]);
+        if (hc[L.nnz] / L.nnz > 2048) {
+            L.gather_chunk = (int32_t)std::max<int64_t>(1024, (maxlen + 63) / 64);
+            L.gather_nchunk = (int32_t)((maxlen + L.gather_chunk - 1) / L.gather_chunk);
+            L.gather_part.alloc((size_t)L.nnz * (size_t)L.gather_nchunk);
+        }
+    }
     if (!selection) {
         // dense R panels per (element, state): p x c, column-major
         std::vector<double> panels((size_t)pp * ecols.size(), 0.0);
@@ -732,7 +745,7 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
                                      nullptr, L.denseW.p + (int64_t)klo * n, ld, L.Hval.p, L.m, false, true, st);
             }
         } else if (L.selection) {
-            launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, d_hel.p, L.Hval.p, L.long_lists, st);
+            launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, d_hel.p, L.Hval.p, L.long_lists, st, L.gather_chunk, L.gather_nchunk, L.gather_part.p);
         } else {
             PanelParams PP;
             PP.p = p; PP.nu = nu; PP.N = N;
@@ -745,7 +758,7 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
                 // staged variant while four workgroups still fit a CU (narrow supports: 2-D hierarchies)
                 if (panel_accumulate_lds(p, nu, L.acc_ctmax) <= 40 * 1024) launch_panel_project_staged(PP, L.acc_ctmax, st);
                 else launch_panel_project(PP, st);
-                launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st);
+                launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st, L.gather_chunk, L.gather_nchunk, L.gather_part.p);
             }
         }
     }

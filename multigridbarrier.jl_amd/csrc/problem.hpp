@@ -54,6 +54,8 @@ struct Level {
     int64_t slab_doubles = 0;
     int32_t cmax = 1;
     bool long_lists = false;
+    int32_t gather_chunk = 0, gather_nchunk = 0;   // very long lists: two-stage gather (chunk length, chunks per list)
+    DevBuf<double> gather_part;
     int64_t nnz = 0;
     // dense (spectral) levels: DR = [D_k R_{state(k)}]_k stacked ((nD*n) x m) and W = Ybar * DR
     DevBuf<double> denseDR, denseW;
