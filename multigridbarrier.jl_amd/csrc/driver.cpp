@@ -195,8 +195,8 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         auto t0 = std::chrono::steady_clock::now();
         int fstatus = MGBHIP_OK;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            P->factor(C.level);
-            P->trisolve(C.level, P->d_g.p, P->d_nv.p);
+            P->factor(C.level, P->d_g.p);                   // the gradient rides along: no forward sweep afterwards
+            P->trisolve_carried(C.level, P->d_nv.p);
             // pivot flag, direction statistics and lambda^2 = <g, n> in one round trip
             launch_vec_stats(P->d_nv.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st);
             launch_dot(P->d_g.p, P->d_nv.p, C.m, P->d_scratch.p, P->d_scal.p + 4, st);

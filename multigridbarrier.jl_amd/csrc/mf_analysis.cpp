@@ -373,23 +373,47 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
         }
     }
 
+    // ---- border unknown (MfOptions::border): last in the order, in every front's boundary, own root front ----
+    std::vector<int32_t> pos_ext;
+    int32_t nsn_all = nsn;
+    if (opt.border) {
+        plan.border = true;
+        pos_ext = b.pos;
+        pos_ext.push_back((int32_t)n);               // after every real unknown
+        std::vector<int32_t> roots;
+        for (int32_t s = 0; s < nsn; ++s) {
+            if (merged_into[s] >= 0) continue;
+            sn_struct[s].push_back((int32_t)n);
+            if (parent[s] < 0) roots.push_back(s);
+        }
+        b.sn_piv.push_back(std::vector<int32_t>{(int32_t)n});
+        sn_struct.emplace_back();
+        sn_child.push_back(roots);
+        for (int32_t r : roots) parent[r] = nsn;
+        parent.push_back(-1);
+        merged_into.push_back(-1);
+        nsn_all = nsn + 1;
+    }
+    const std::vector<int32_t>& posx = opt.border ? pos_ext : b.pos;
+    const int64_t nnz_h = rowptr[n];
+
     // ---- levels, final numbering ----------------------------------------------------------
-    std::vector<int32_t> level(nsn, 0);
-    for (int32_t s = 0; s < nsn; ++s) {
+    std::vector<int32_t> level(nsn_all, 0);
+    for (int32_t s = 0; s < nsn_all; ++s) {
         if (merged_into[s] >= 0) continue;
         int32_t l = 0;
         for (int32_t c : sn_child[s]) l = std::max(l, level[c] + 1);
         level[s] = l;
     }
     std::vector<int32_t> live;
-    for (int32_t s = 0; s < nsn; ++s)
+    for (int32_t s = 0; s < nsn_all; ++s)
         if (merged_into[s] < 0) live.push_back(s);
     auto msize = [&](int32_t s) { return (int32_t)(b.sn_piv[s].size() + sn_struct[s].size()); };
     std::stable_sort(live.begin(), live.end(), [&](int32_t a, int32_t c2) {
         if (level[a] != level[c2]) return level[a] < level[c2];
         return msize(a) < msize(c2);
     });
-    std::vector<int32_t> newid(nsn, -1);
+    std::vector<int32_t> newid(nsn_all, -1);
     for (size_t i = 0; i < live.size(); ++i) newid[live[i]] = (int32_t)i;
 
     const int32_t nf = (int32_t)live.size();
@@ -428,7 +452,7 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
     for (int32_t l = 0; l <= maxlevel; ++l) plan.level_ptr[l + 1] += plan.level_ptr[l];
 
     // ---- relative indices + A scatter lists ------------------------------------------------
-    std::vector<int32_t> loc(n, -1);
+    std::vector<int32_t> loc(n + 1, -1);
     // rel: positions of a front's boundary inside its parent's index list
     for (int32_t i = 0; i < nf; ++i) {
         Front& f = plan.fronts[i];
@@ -455,9 +479,14 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
         for (int32_t lv = 0; lv < f.k; ++lv) {
             plan.a_colptr.push_back((int32_t)((int64_t)plan.a_src.size() - f.a_off));
             int32_t v = idx[lv];
+            if (v == n) {                       // the border's own 1 x 1 front: entry (n, n)
+                plan.a_src.push_back((int32_t)(nnz_h + n));
+                plan.a_dst.push_back(lv + lv * f.m);
+                continue;
+            }
             for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
                 int32_t u = colidx[e];
-                if (u != v && pos[u] < pos[v]) continue;
+                if (u != v && posx[u] < posx[v]) continue;
                 int32_t lu = loc[u];
                 if (lu < 0 || lu < lv) throw std::runtime_error("mf_analyze: structure violation in A scatter");
                 int32_t src = e;
@@ -470,6 +499,12 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
                 }
                 plan.a_src.push_back(src);
                 plan.a_dst.push_back(lu + lv * f.m);
+            }
+            if (opt.border) {                   // border column entry (n, v): last row of the front
+                if (loc[n] != f.m - 1) throw std::runtime_error("mf_analyze: border is not the last row of a front");
+                if (nnz_h + n >= (int64_t)INT32_MAX) throw std::runtime_error("mf_analyze: bordered value index exceeds 32 bits");
+                plan.a_src.push_back((int32_t)(nnz_h + v));
+                plan.a_dst.push_back((f.m - 1) + lv * f.m);
             }
         }
         f.a_cnt = (int32_t)((int64_t)plan.a_src.size() - f.a_off);

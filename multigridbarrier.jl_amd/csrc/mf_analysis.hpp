@@ -38,7 +38,8 @@ struct Front {
 };
 
 struct MfPlan {
-    int64_t n = 0;
+    int64_t n = 0;                      // unknowns of H (the border, if any, is unknown n)
+    bool border = false;
     std::vector<Front> fronts;          // sorted by (level, size class)
     std::vector<int32_t> front_idx;     // concatenated index lists (global node ids)
     std::vector<int32_t> children;      // concatenated child front ids
@@ -63,6 +64,13 @@ struct MfOptions {
     double sep_weight = 1.5;      // separator-size penalty in the bisection score
     int32_t merge_max_m = 0;      // relaxed amalgamation: merge a child into its parent while m stays <= this
     int32_t exact_merge_max_m = 128;  // exact-fit amalgamation only while the merged front stays this small
+    // Bordered system [H c; c' gamma]: one extra unknown (id n), adjacent to every other and eliminated last.
+    // It is appended to the boundary of every front and gets a 1 x 1 root front of its own.  With c = -g the
+    // factorization carries the forward substitution of H x = g along as an extra row of every front, and a
+    // backward sweep from x_n = 1 returns x = H^{-1} g (MfSolver::solve_border); with c = 0, gamma = 1 the
+    // bordered system is block diagonal and ordinary solves are unchanged.  Values of the border column are read
+    // from the tail of the value array: entry (v, n) at nnz + v, entry (n, n) at nnz + n.
+    bool border = false;
 };
 
 // Symmetric pattern in CSR (both triangles present, diagonal optional).  Values are not

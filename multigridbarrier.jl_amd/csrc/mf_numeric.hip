@@ -1779,6 +1779,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     if (const char* e = getenv("MGBHIP_SEPW")) opt.sep_weight = atof(e);
     if (const char* e = getenv("MGBHIP_MERGE")) opt.merge_max_m = atoi(e);
     if (const char* e = getenv("MGBHIP_NO_GEO"); e && e[0] == '1') coords = nullptr;
+    opt.border = true;          // every system is factored bordered (mf_analysis.hpp): the Newton solve needs no forward sweep
     mf_analyze(n, rowptr, colidx, opt, plan, coords, dim);
     const int32_t nf = (int32_t)plan.fronts.size();
     std::vector<FrontDev> fd(nf);
@@ -1823,7 +1824,14 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     d_a_colptr.upload(plan.a_colptr, st);
     d_arena.alloc((size_t)std::max<int64_t>(plan.arena_doubles, 1));
     d_uvec.alloc((size_t)std::max<int64_t>(plan.uvec_doubles, 1));
-    d_y.alloc((size_t)std::max<int64_t>(plan.n, 1));
+    d_y.alloc((size_t)plan.n + 1);            // + the border unknown
+    d_bx.alloc((size_t)plan.n + 1);
+    d_xx.alloc((size_t)plan.n + 1);
+    {
+        const double one = 1.0;
+        d_one.upload(&one, 1, st);
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
+    }
     d_tbig.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
     d_tsol.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
     d_dvec.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
@@ -1951,7 +1959,8 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                                    L.count, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
             } else if (L.cls) {
                 static const int nbt_mid = [] { const char* e = getenv("MGBHIP_NBT"); return e ? atoi(e) : 8; }();
-                const int threads = L.cls <= 16 ? 64 : (L.cls <= 32 ? 128 : 256);
+                static const int thr_mid = [] { const char* e = getenv("MGBHIP_SMALL_THREADS"); return e ? atoi(e) : 256; }();
+                const int threads = L.cls <= 16 ? 64 : (L.cls <= 32 ? 128 : (L.cls <= 64 ? thr_mid : 256));
                 const int nbt = L.cls <= 16 ? 8 : std::min(nbt_mid, 16);    // 32-column LDS panels do not fit beside a 128 x 128 front
                 const int nbt_alloc = nbt <= 8 ? 8 : (nbt <= 16 ? 16 : 32);
                 const size_t lds = (size_t)(L.cls * L.cls + nbt_alloc * L.cls) * sizeof(double);    // front + scaled panel
@@ -2006,6 +2015,31 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
 void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers* timers) {
     MGB_REQUIRE(analyzed, "MfSolver::solve before analyze");
     if (timers) timers->begin("trisolve");
+    // the factored system is [H c; c' gamma] with c = 0 (set_border_identity): solve it for [b; 0]
+    const size_t n = (size_t)plan.n;
+    MGB_HIP_CHECK(hipMemcpyAsync(d_bx.p, d_b, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    MGB_HIP_CHECK(hipMemsetAsync(d_bx.p + n, 0, sizeof(double), st));
+    forward_pass(d_bx.p, st, timers);
+    backward_pass(d_xx.p, st, timers);
+    MGB_HIP_CHECK(hipMemcpyAsync(d_x, d_xx.p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    MGB_HIP_CHECK(hipGetLastError());
+    if (timers) timers->end();
+}
+
+void MfSolver::solve_border(double* d_x_np1, hipStream_t st, StageTimers* timers) {
+    MGB_REQUIRE(analyzed, "MfSolver::solve_border before analyze");
+    if (timers) timers->begin("trisolve");
+    // factors of [H -g; -g' -1]: the forward substitution of H x = g already ran as the border row of every
+    // front.  L' x = e_n backwards from x_n = 1 gives x[0:n] = H^{-1} g.
+    const size_t n = (size_t)plan.n;
+    MGB_HIP_CHECK(hipMemsetAsync(d_y.p, 0, n * sizeof(double), st));
+    MGB_HIP_CHECK(hipMemcpyAsync(d_y.p + n, d_one.p, sizeof(double), hipMemcpyDeviceToDevice, st));
+    backward_pass(d_x_np1, st, timers);
+    MGB_HIP_CHECK(hipGetLastError());
+    if (timers) timers->end();
+}
+
+void MfSolver::forward_pass(const double* d_b, hipStream_t st, StageTimers* timers) {
     static const bool lvl_timing = [] { const char* e = getenv("MGBHIP_LEVEL_TIMING"); return e && e[0] == '1'; }();
     int lvno = -1;
     for (auto& lev : level_solves) {
@@ -2046,6 +2080,10 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
             }
         }
     }
+}
+
+void MfSolver::backward_pass(double* d_x, hipStream_t st, StageTimers* timers) {
+    static const bool lvl_timing = [] { const char* e = getenv("MGBHIP_LEVEL_TIMING"); return e && e[0] == '1'; }();
     for (int32_t l = (int32_t)level_solves.size() - 1; l >= 0; --l) {
         char nm[32];
         snprintf(nm, sizeof(nm), "bwd_lv%02d", l);
@@ -2080,8 +2118,6 @@ void MfSolver::solve(const double* d_b, double* d_x, hipStream_t st, StageTimers
             }
         }
     }
-    MGB_HIP_CHECK(hipGetLastError());
-    if (timers) timers->end();
 }
 
 #ifdef MGB_STEP_PROBE

@@ -33,8 +33,15 @@ class MfSolver {
     // factor the matrix whose CSR values (same pattern as analyze) live at d_values.
     // Asynchronous; the not-SPD flag is read back by status().
     void factor(const double* d_values, hipStream_t st, StageTimers* timers);
-    // x = A^{-1} b (device vectors of length n; x may alias b)
+    // Every system is factored BORDERED, [H c; c' gamma] (MfOptions::border): the value array passed to factor()
+    // carries the border column in its tail, d_values[nnz + v] = c_v (v < n) and d_values[nnz + n] = gamma.
+    //   c = 0, gamma = 1:  block diagonal; solve() is the ordinary forward + backward sweep of H x = b.
+    //   c = -g, gamma = -1: the forward substitution of H x = g rides along the factorization as the last row of
+    //                       every front; solve_border() is ONE backward sweep from x_n = 1 and returns H^{-1} g.
+    // x = H^{-1} b (device vectors of length n; x may alias b); factors must come from a c = 0 border
     void solve(const double* d_b, double* d_x, hipStream_t st, StageTimers* timers);
+    // x[0:n] = H^{-1} g for factors of the c = -g border; d_x_np1 has room for n + 1 doubles (x[n] = 1 on return)
+    void solve_border(double* d_x_np1, hipStream_t st, StageTimers* timers);
     int status(hipStream_t st);     // synchronises; MGBHIP_OK or MGBHIP_ERR_NOT_SPD
     // enqueue the copy of the flag only (pinned destination); interpret it after the caller's sync
     void status_async(int32_t* h_dst, hipStream_t st) const;
@@ -49,6 +56,9 @@ class MfSolver {
     bool factored_inv = false;
 
    private:
+    void forward_pass(const double* d_b_np1, hipStream_t st, StageTimers* timers);
+    void backward_pass(double* d_x_np1, hipStream_t st, StageTimers* timers);
+    DevBuf<double> d_bx, d_xx, d_one;     // bordered right-hand side / solution of solve(), the constant 1
     DevBuf<FrontDev> d_fronts;
     DevBuf<int32_t> d_front_idx, d_children, d_rel, d_a_src, d_a_dst, d_a_colptr;
     DevBuf<int64_t> d_ug_ptr, d_ug_src;   // per large front: for every local index the children's update-vector entries, in child order

@@ -221,7 +221,7 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     P->d_scal.alloc(16);
     P->d_scratch.alloc((size_t)reduce_scratch_doubles(std::max<int64_t>(mmax, (int64_t)zn)));
     P->d_nodeF.alloc((size_t)P->n);
-    P->d_x.alloc(mmax); P->d_g.alloc(mmax); P->d_nv.alloc(mmax); P->d_xn.alloc(mmax);
+    P->d_x.alloc(mmax); P->d_g.alloc(mmax); P->d_nv.alloc(mmax + 1); P->d_xn.alloc(mmax);   // d_nv: + the border entry of solve_border
     P->d_gn.alloc(mmax); P->d_tmp.alloc(std::max<size_t>(mmax, zn));   // d_tmp also holds the t-ramp's roll-back copy of z
     {
         size_t tch = 1;
@@ -253,7 +253,7 @@ void mgbhip_problem::ensure_plan_dense(int level) {
     L.nnz = m * m;
     L.Hptr.upload(L.hHptr, st);
     L.Hcol.upload(L.hHcol, st);
-    L.Hval.alloc((size_t)std::max<int64_t>(L.nnz, 1));
+    L.Hval.alloc((size_t)(L.nnz + L.m + 1));       // + the border column of the bordered factorization (mf_solver.hpp)
     L.selection = false;
     const int64_t ld = (int64_t)nD * nn;
     L.denseDR.alloc((size_t)std::max<int64_t>(ld * m, 1));
@@ -491,7 +491,7 @@ void mgbhip_problem::ensure_plan(int level) {
         L.Hptr.upload(L.hHptr, st);
         L.Hcol.upload(L.hHcol, st);
     }
-    L.Hval.alloc((size_t)L.nnz);
+    L.Hval.alloc((size_t)(L.nnz + L.m + 1));        // + the border column of the bordered factorization (mf_solver.hpp)
     L.selection = selection;
     const int NB = hel_blocks(nu);
     // 3. contribution lists: every structural nonzero of H gathers its summands from a slab in
@@ -767,7 +767,7 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
     cnt.f2++;
 }
 
-void mgbhip_problem::factor(int level) {
+void mgbhip_problem::factor(int level, const double* rhs) {
     Level& L = levels[level];
     MGB_REQUIRE(L.have_H, "solve requested before any Hessian was assembled at this level");
     hipStream_t st = stream();
@@ -795,6 +795,15 @@ void mgbhip_problem::factor(int level) {
             fprintf(stderr, "[mgbhip] symbolic analysis level %d (m=%lld, nnz=%lld): %.2f s\n", level, (long long)L.m,
                     (long long)L.nnz, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
+    if (rhs) {          // border column -g, corner -1: the factorization carries the forward substitution of H x = g
+        launch_scale_copy(rhs, -1.0, L.Hval.p + L.nnz, L.m, st);
+        launch_fill(-1.0, L.Hval.p + L.nnz + L.m, 1, st);
+        L.border_state = 2;
+    } else if (L.border_state != 1) {       // border column 0, corner 1: block diagonal, ordinary solves
+        MGB_HIP_CHECK(hipMemsetAsync(L.Hval.p + L.nnz, 0, sizeof(double) * (size_t)L.m, st));
+        launch_fill(1.0, L.Hval.p + L.nnz + L.m, 1, st);
+        L.border_state = 1;
+    }
     L.solver.factor(L.Hval.p, st, &ctx->timers);
     L.factored = true;
     cnt.factor++;
@@ -803,5 +812,12 @@ void mgbhip_problem::factor(int level) {
 void mgbhip_problem::trisolve(int level, const double* d_g, double* d_xout) {
     Level& L = levels[level];
     MGB_REQUIRE(L.factored, "triangular solve before factorization");
+    MGB_REQUIRE(L.border_state == 1, "triangular solve on factors that carry a Newton right-hand side");
     L.solver.solve(d_g, d_xout, stream(), &ctx->timers);
+}
+
+void mgbhip_problem::trisolve_carried(int level, double* d_xout_np1) {
+    Level& L = levels[level];
+    MGB_REQUIRE(L.factored && L.border_state == 2, "carried solve without a factorization that carries the right-hand side");
+    L.solver.solve_border(d_xout_np1, stream(), &ctx->timers);
 }

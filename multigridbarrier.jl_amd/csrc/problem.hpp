@@ -61,6 +61,7 @@ struct Level {
     DevBuf<double> denseDR, denseW;
     MfSolver solver;
     bool have_H = false, factored = false;
+    int border_state = 0;                 // tail of Hval: 0 unset, 1 identity border (solve), 2 Newton right-hand side (solve_border)
 };
 
 struct Counters {
@@ -114,6 +115,10 @@ struct mgbhip_problem {
     void eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
     void eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc);
     // returns MGBHIP_OK or MGBHIP_ERR_NOT_SPD; x = H^{-1} g on the device
-    void factor(int level);
+    // rhs == nullptr: factor H for ordinary solves (trisolve).  rhs = g: factor the bordered matrix [H -g; -g' -1],
+    // which performs the forward substitution of H x = g inside the factorization; trisolve_carried then needs the
+    // backward sweep only (the Newton loop's one solve per factorization).
+    void factor(int level, const double* rhs = nullptr);
     void trisolve(int level, const double* d_g, double* d_xout);
+    void trisolve_carried(int level, double* d_xout_np1);      // output has room for m + 1 doubles
 };
