@@ -32,6 +32,13 @@ namespace mgbhip {
 
 namespace {
 
+#ifdef MGB_STEP_PROBE      // development probe build only (tools/gpu_probe.py)
+__device__ long long g_probe[64];
+#define SP(i) do { if (threadIdx.x == 0 && gridDim.x > 8000 && gridDim.x < 8400 && blockIdx.x == 4096) g_probe[40 + i] = wall_clock64(); } while (0)
+#else
+#define SP(i) do { } while (0)
+#endif
+
 constexpr int TX = 16;    // row lanes of the 2-D thread maps
 constexpr int NB = 32;    // panel width of the large-front path
 constexpr int CT = 8;     // destination columns per workgroup in the large-front assembly (2 per wave)
@@ -116,10 +123,30 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     const int mm = m * m;
     double* S = W + mm;                        // [NBT][m] scaled multipliers of the current panel
 
+    SP(0);
+    // the first batch of A entries and the first chunk of child descriptors are requested before the LDS front is
+    // zeroed: two dependent-load chains (a_src -> Hval, children -> fr) run under the fill instead of after it
+    int a_d0 = -1;
+    double a_v0 = 0.0;
+    if (tid < F.a_cnt) {
+        a_d0 = a_dst[F.a_off + tid];
+        a_v0 = Hval[a_src[F.a_off + tid]];
+    }
+    int64_t pU = 0, pR = 0;
+    int32_t pM = 0, pB = 0;
+    if (tid < min(CHILD_CHUNK, F.nchild)) {
+        const FrontDev C = fr[children[F.child_off + tid]];
+        pU = C.F_off + (int64_t)C.k * C.m + C.k;
+        pR = C.rel_off;
+        pM = C.m;
+        pB = C.m - C.k;
+    }
     for (int i = tid; i < mm; i += nt) W[i] = 0.0;
     __syncthreads();
-    for (int t = tid; t < F.a_cnt; t += nt) W[a_dst[F.a_off + t]] = Hval[a_src[F.a_off + t]];
+    if (a_d0 >= 0) W[a_d0] = a_v0;
+    for (int t = tid + nt; t < F.a_cnt; t += nt) W[a_dst[F.a_off + t]] = Hval[a_src[F.a_off + t]];
     __syncthreads();
+    SP(1);
     // Extend-add of the children.  The additions of different children may hit the same slot, so
     // children stay ordered (deterministic sums) with a barrier between them -- but their global
     // loads do not have to: the child descriptors are fetched once into LDS, and the entries of
@@ -135,14 +162,64 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
         const int nc = min(CHILD_CHUNK, F.nchild - cbase);
         __syncthreads();
         if (tid < nc) {
-            const FrontDev C = fr[children[F.child_off + cbase + tid]];
-            cU[tid] = C.F_off + (int64_t)C.k * C.m + C.k;
-            cR[tid] = C.rel_off;
-            cM[tid] = C.m;
-            cB[tid] = C.m - C.k;
+            if (cbase == 0) {
+                cU[tid] = pU; cR[tid] = pR; cM[tid] = pM; cB[tid] = pB;
+            } else {
+                const FrontDev C = fr[children[F.child_off + cbase + tid]];
+                cU[tid] = C.F_off + (int64_t)C.k * C.m + C.k;
+                cR[tid] = C.rel_off;
+                cM[tid] = C.m;
+                cB[tid] = C.m - C.k;
+            }
         }
         __syncthreads();
         for (int c0 = 0; c0 < nc; c0 += 4) {
+            if (nt == 256 && (c0 & 15) == 0) {
+                // Sixteen small children (update block <= 8 x 8) at once: wave w takes children 4w .. 4w+3, one entry
+                // per lane, so ALL their loads are in flight together (one memory latency for the group instead
+                // of four).  The additions keep child order: a wave applies its four children in program order
+                // (LDS operations of one wave stay ordered) and the waves take turns, four barriers in all.
+                const int ng = min(16, nc - c0);
+                bool small16 = true;
+                for (int u = 0; u < ng; ++u) small16 = small16 && cB[c0 + u] * cB[c0 + u] <= 64;
+                if (small16) {
+                    const int w = tid >> 6, e = tid & 63;
+                    int dst[4];
+                    double val[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        dst[u] = -1;
+                        val[u] = 0.0;
+                        const int c = c0 + 4 * w + u;
+                        if (4 * w + u < ng) {
+                            const int b = cB[c];
+                            if (e < b * b) {
+                                const int j = e / b, r = e - j * b;
+                                if (r >= j) {
+                                    const int32_t* rl = rel + cR[c];
+                                    dst[u] = rl[r] + rl[j] * m;
+                                    val[u] = arena[cU[c] + (int64_t)j * cM[c] + r];
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph) {
+                        if (4 * ph < ng) {
+                            if (ph == w) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    if (dst[u] >= 0) W[dst[u]] += val[u];
+                                    wave_sync();            // child u's stores before child u+1's loads
+                                }
+                            }
+                            __syncthreads();
+                        }
+                    }
+                    c0 += 12;          // the loop increment adds the other 4
+                    continue;
+                }
+            }
             int dst[4];
             double val[4];
 #pragma unroll
@@ -194,6 +271,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
             }
         }
     }
+    SP(2);
     bool bad = false;
     for (int j0 = 0; j0 < k; j0 += NBT) {
         const int nb = min(NBT, k - j0);
@@ -268,8 +346,10 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
         }
         __syncthreads();
     }
+    SP(3);
     if (bad && tid == 0) atomicOr(status, 1);
     for (int i = tid; i < mm; i += nt) Fg[i] = W[i];
+    SP(4);
 }
 
 // Triangular solves of small fronts: one wave per front (4 fronts per workgroup), the work
@@ -1293,7 +1373,6 @@ __device__ __forceinline__ void slice_transform(double (*P)[ST + 1], double (*Po
 }
 
 #ifdef MGB_STEP_PROBE      // development probe build only (tools/gpu_probe.py): per-phase timestamps of one step
-__device__ long long g_probe[64];
 #define PROBE(i) do { if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[i] = wall_clock64(); if (!is_la && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[16 + i] = wall_clock64(); } while (0)
 #else
 #define PROBE(i) do { } while (0)
