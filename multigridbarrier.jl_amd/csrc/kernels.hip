@@ -454,6 +454,110 @@ __global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
         }
 }
 
+// Specialised line-search trial (MODE_F01 of the generic kernel: value and gradient at one point from one
+// pass over the operator blocks) for compile-time (NY, P) and D-table signature: every loop unrolled, the
+// set-membership tests of the D table folded away.  Same arithmetic, same summation order.
+template <int NY, int P, class Sig>
+__global__ __launch_bounds__(256) void elem_f01_fast(const ElemParams Pm) {
+    constexpr int G = (P <= 2) ? 2 : (P <= 4) ? 4 : (P <= 8) ? 8 : (P <= 16) ? 16 : (P <= 32) ? 32 : 64;
+    constexpr int EPB = 256 / G;
+    constexpr int PP = P * P;
+    extern __shared__ double sh[];
+    const int tid = threadIdx.x;
+    const int el = tid / G;
+    const int r = tid % G;
+    const int nu = Sig::rt ? Pm.nu : 2;
+    auto DST = [&](int k) -> int { return Sig::rt ? Pm.D_state[k] : Sig::state(k); };
+    auto DSG = [&](int k) -> int { return Sig::rt ? Pm.D_stage[k] : Sig::stage(k); };
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    const int64_t e = e0 + el;
+    const bool active = (e < Pm.N) && (r < P);
+    const int64_t n = Pm.n;
+    const int64_t node = e * P + r;
+
+    double* zl = sh;                                    // [EPB][nu][G]
+    double* opL = zl + 256 * nu;                        // [nstage][EPB][PP]
+    double* YL = opL + (size_t)Pm.nstage * EPB * PP;    // [EPB][NY][G]
+    {
+        int64_t lim = (Pm.N - e0) * PP;
+        if (lim > (int64_t)EPB * PP) lim = (int64_t)EPB * PP;
+        for (int o = 0; o < Pm.nstage; ++o) {
+            const double* src = Pm.stage_ptr[o] + e0 * PP;
+            double* dst = opL + (size_t)o * EPB * PP;
+            for (int i = tid; i < lim; i += 256) dst[i] = src[i];
+        }
+    }
+    // the node's cost row and weights do not depend on anything staged: request them with the operators
+    double ck[NY];
+    double wv = 0.0, bwv = 0.0;
+    if (active) {
+        for (int a = 0; a < nu; ++a) zl[(el * nu + a) * G + r] = Pm.z0[(int64_t)a * n + node];
+#pragma unroll
+        for (int k = 0; k < NY; ++k) ck[k] = Pm.c[node + n * k];
+        wv = Pm.w[node];
+        bwv = Pm.bw ? Pm.bw[node] : 0.0;
+    }
+    __syncthreads();
+    const double* opE = opL + (size_t)el * PP;
+    auto OP = [&](int k, int rr, int cc) -> double { return opE[(size_t)DSG(k) * EPB * PP + cc * P + rr]; };
+    double y[NY];
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+        double v = 0.0;
+        if (active) {
+            const double* za = zl + (el * nu + DST(k)) * G;
+            if (DSG(k) < 0) v = za[r];
+            else {
+#pragma unroll
+                for (int cc = 0; cc < P; ++cc) v += OP(k, r, cc) * za[cc];
+            }
+        }
+        y[k] = v;
+    }
+    double val = 0.0;
+    if (active) {
+        double F0v, F, g[NY], H[NY * NY];
+        cone_eval<NY, 0>(Pm.cone, node, n, y, F0v, g, H);
+        cone_eval<NY, 1>(Pm.cone, node, n, y, F, g, H);
+        const double bar = Pm.bw ? ((bwv == 0.0) ? 0.0 : bwv * F0v) : Pm.invn * F0v;
+        double lin = 0.0;
+#pragma unroll
+        for (int k = 0; k < NY; ++k) {
+            lin += ck[k] * y[k];
+            const double sc = Pm.bw ? ((bwv == 0.0) ? 0.0 : bwv * g[k]) : Pm.invn * g[k];
+            YL[(el * NY + k) * G + r] = sc + wv * ck[k];
+        }
+        val = bar + wv * lin;
+    }
+    __syncthreads();
+    if (active) {
+        const int i = r;
+        for (int a = 0; a < nu; ++a) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < NY; ++k) {
+                if (DST(k) != a) continue;
+                const double* Yk = YL + (el * NY + k) * G;
+                if (DSG(k) < 0) {
+                    acc += Yk[i];
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < P; ++rr) acc += OP(k, rr, i) * Yk[rr];
+                }
+            }
+            Pm.out_ret[(int64_t)a * n + node] = acc;
+        }
+    }
+    __syncthreads();            // operators / Y no longer needed: reuse LDS for the reduction
+    sh[tid] = val;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] += sh[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) Pm.out_partial[blockIdx.x] = sh[0];
+}
+
 // ---- reductions ------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t count,
@@ -1047,6 +1151,30 @@ static bool try_f2_fast(const ElemParams& P, hipStream_t st) {
     return true;
 }
 
+template <int NY, int PN>
+static bool try_f01_fast(const ElemParams& P, hipStream_t st) {
+    if (P.nD != NY || P.p != PN) return false;
+    for (int k = 0; k < NY; ++k)
+        if (P.D_stage[k] == -2) return false;          // operators not staged: generic path
+    const int G = elem_group(PN);
+    const int EPB = 256 / G;
+    size_t lds = (256 * (size_t)P.nu + (size_t)P.nstage * EPB * PN * PN + (size_t)EPB * NY * G) * sizeof(double);
+    if (lds < 256 * sizeof(double)) lds = 256 * sizeof(double);
+    if (lds > 160 * 1024) return false;
+    static bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)elem_f01_fast<NY, PN, SigRuntime>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)elem_f01_fast<NY, PN, SigDefault<NY>>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        return true;
+    }();
+    (void)attr;
+    if (is_default_signature<NY>(P))
+        hipLaunchKernelGGL((elem_f01_fast<NY, PN, SigDefault<NY>>), dim3((unsigned)elem_grid(PN, P.N)), dim3(256), lds, st, P);
+    else
+        hipLaunchKernelGGL((elem_f01_fast<NY, PN, SigRuntime>), dim3((unsigned)elem_grid(PN, P.N)), dim3(256), lds, st, P);
+    return true;
+}
+
 void launch_elem(const ElemParams& P, int mode, hipStream_t st) {
     if (P.p > 64) {      // one dense spectral element: GEMV + node kernel path (dense.hip)
         launch_dense_eval(P, mode, st);
@@ -1060,6 +1188,14 @@ void launch_elem(const ElemParams& P, int mode, hipStream_t st) {
         if (try_f2_fast<4, 7>(P, st) || try_f2_fast<3, 2>(P, st) || try_f2_fast<5, 8>(P, st) ||
             try_f2_fast<4, 6>(P, st) || try_f2_fast<7, 7>(P, st) || try_f2_fast<6, 2>(P, st) ||
             try_f2_fast<8, 8>(P, st) || try_f2_fast<7, 6>(P, st)) {
+            MGB_HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
+    if (mode == MODE_F01) {
+        if (try_f01_fast<4, 7>(P, st) || try_f01_fast<3, 2>(P, st) || try_f01_fast<5, 8>(P, st) ||
+            try_f01_fast<4, 6>(P, st) || try_f01_fast<7, 7>(P, st) || try_f01_fast<6, 2>(P, st) ||
+            try_f01_fast<8, 8>(P, st) || try_f01_fast<7, 6>(P, st)) {
             MGB_HIP_CHECK(hipGetLastError());
             return;
         }
