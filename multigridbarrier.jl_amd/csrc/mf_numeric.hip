@@ -469,6 +469,88 @@ __global__ __launch_bounds__(256) void mf_backward_small(const FrontDev* __restr
 // large fronts: batched multi-workgroup kernels (grid.y = front within the batch)
 // ------------------------------------------------------------------------------------------------
 
+// Gather form of the assembly for fronts with few children (every front of a nested-dissection tree above the
+// leaves has two to four): the inverse of every child's relative index list is laid out in LDS, then each
+// destination entry is formed ONCE in a register -- the children's entries that land on it, added in child order,
+// all their loads in flight together -- and stored once.  No zero pass, no read-modify-write of the arena, and
+// the dependent-load chains of the children run side by side instead of one child after the other.
+constexpr int GATHER_MAX_CHILD = 8;
+__global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict__ fr, int32_t first,
+                                                     const int32_t* __restrict__ children,
+                                                     const int32_t* __restrict__ rel,
+                                                     const int32_t* __restrict__ a_src,
+                                                     const int32_t* __restrict__ a_dst,
+                                                     const int32_t* __restrict__ a_colptr,
+                                                     const double* __restrict__ Hval, double* __restrict__ arena, int mstride) {
+    extern __shared__ int32_t inv[];               // [nchild][mstride]: position in the child's update block or -1
+    __shared__ int64_t cU[GATHER_MAX_CHILD];
+    __shared__ int64_t cR[GATHER_MAX_CHILD];
+    __shared__ int32_t cM[GATHER_MAX_CHILD], cB[GATHER_MAX_CHILD];
+    const FrontDev F = fr[first + blockIdx.y];
+    const int m = F.m;
+    const int c0 = blockIdx.x * CT;
+    if (c0 >= m) return;
+    const int c1 = min(c0 + CT, m);
+    double* W = arena + F.F_off;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;     // one wave per destination column, lanes on the rows
+    const int nch = F.nchild;
+    if (tid < nch) {
+        const FrontDev C = fr[children[F.child_off + tid]];
+        cU[tid] = C.F_off + (int64_t)C.k * C.m + C.k;
+        cR[tid] = C.rel_off;
+        cM[tid] = C.m;
+        cB[tid] = C.m - C.k;
+    }
+    for (int i = tid; i < nch * mstride; i += 256) inv[i] = -1;
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int32_t* rl = rel + cR[ch];
+        const int b = cB[ch];
+        for (int j = tid; j < b; j += 256) inv[ch * mstride + rl[j]] = j;
+    }
+    __syncthreads();
+    for (int c = c0 + wave; c < c1; c += 4) {
+        double* Wc = W + (int64_t)c * m;
+        int64_t colbase[GATHER_MAX_CHILD];         // child column offset, -1 when the child does not reach column c
+#pragma unroll
+        for (int ch = 0; ch < GATHER_MAX_CHILD; ++ch) {
+            const int jc = ch < nch ? inv[ch * mstride + c] : -1;
+            colbase[ch] = jc >= 0 ? cU[ch] + (int64_t)jc * cM[ch] : -1;
+        }
+        for (int r = c + lane; r < m; r += 128) {  // two rows per lane in flight
+            const int r1 = r + 64;
+            double u0[GATHER_MAX_CHILD], u1[GATHER_MAX_CHILD];
+#pragma unroll
+            for (int ch = 0; ch < GATHER_MAX_CHILD; ++ch) {
+                u0[ch] = 0.0;
+                u1[ch] = 0.0;
+                if (colbase[ch] >= 0) {
+                    const int i0 = inv[ch * mstride + r];
+                    const int i1 = r1 < m ? inv[ch * mstride + r1] : -1;
+                    if (i0 >= 0) u0[ch] = arena[colbase[ch] + i0];
+                    if (i1 >= 0) u1[ch] = arena[colbase[ch] + i1];
+                }
+            }
+            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < GATHER_MAX_CHILD; ++ch) {      // child order: the summation order of the extend-add
+                v0 += u0[ch];
+                v1 += u1[ch];
+            }
+            Wc[r] = v0;
+            if (r1 < m) Wc[r1] = v1;
+        }
+    }
+    __syncthreads();
+    {   // A entries are grouped by pivot column: the per-column offsets give the range of [c0, c1)
+        const int32_t* cp = a_colptr + F.acol_off;
+        const int beg = cp[min(c0, F.k)], end = cp[min(c1, F.k)];
+        const int32_t* ad = a_dst + F.a_off;
+        for (int t = beg + tid; t < end; t += 256) W[ad[t]] += Hval[a_src[F.a_off + t]];
+    }
+}
+
 // Assembly of destination columns [c0, c0 + CT): zero, scatter A, extend-add the children.
 __global__ __launch_bounds__(256) void mf_big_assemble(const FrontDev* __restrict__ fr, int32_t first,
                                                        const int32_t* __restrict__ children,
@@ -1970,7 +2052,10 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             // the barrier method drives to the edge of singularity, where substitution is the safer arithmetic)
             L.inv = (cls == 0 && L.max_m <= BIG_INV_MAX_M && inv_ok && plan.n >= 1024);
             uses_inv = uses_inv || L.inv;
-            for (int32_t q = i; q < j; ++q) L.max_k = std::max(L.max_k, plan.fronts[q].k);
+            for (int32_t q = i; q < j; ++q) {
+                L.max_k = std::max(L.max_k, plan.fronts[q].k);
+                L.max_child = std::max(L.max_child, plan.fronts[q].nchild);
+            }
             level_launches[l].push_back(L);
             i = j;
         }
@@ -2019,6 +2104,16 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
 static StageTimers g_dummy_timers;
 static StageTimers* timers_or_dummy(StageTimers* t, bool on) { return (t && on) ? t : &g_dummy_timers; }
 
+void MfSolver::launch_big_assemble(const MfLaunch& L, dim3 ga, const double* d_values, hipStream_t st) {
+    const size_t lds = (size_t)L.max_child * (size_t)L.max_m * sizeof(int32_t);
+    if (L.max_child >= 1 && L.max_child <= GATHER_MAX_CHILD && lds <= 60 * 1024)
+        hipLaunchKernelGGL(mf_big_gather, ga, dim3(256), lds, st, d_fronts.p, L.first, d_children.p, d_rel.p, d_a_src.p,
+                           d_a_dst.p, d_a_colptr.p, d_values, d_arena.p, L.max_m);
+    else
+        hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p, d_a_src.p,
+                           d_a_dst.p, d_a_colptr.p, d_values, d_arena.p);
+}
+
 void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timers) {
     MGB_REQUIRE(analyzed, "MfSolver::factor before analyze");
     if (timers) timers->begin("factor");
@@ -2054,8 +2149,7 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                                        d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
             } else if (L.inv && !robust) {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
-                hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,
-                                   d_a_src.p, d_a_dst.p, d_a_colptr.p, d_values, d_arena.p);
+                launch_big_assemble(L, ga, d_values, st);
                 // many fronts: factor block 0 once per front up front instead of inside every tile of step 0
                 const bool pre_diag = L.count >= 24;
                 if (pre_diag)
@@ -2070,8 +2164,7 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 }
             } else {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
-                hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p,
-                                   d_a_src.p, d_a_dst.p, d_a_colptr.p, d_values, d_arena.p);
+                launch_big_assemble(L, ga, d_values, st);
                 for (int j0 = 0; j0 < L.max_k; j0 += NB) {
                     const int rem = L.max_m - j0;                // rows from the panel start, at most
                     const dim3 gp(std::max(1, (rem - 1 + TR - 1) / TR), L.count);

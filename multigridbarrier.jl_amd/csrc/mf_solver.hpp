@@ -20,6 +20,7 @@ struct MfLaunch {          // one kernel launch: a contiguous range of fronts of
     int32_t first, count;
     int32_t cls;           // LDS working size (0 = large-front multi-workgroup path)
     int32_t max_m, max_k;  // largest front / pivot block in the range
+    int32_t max_child = 0; // most children of a front in the range
     bool tiny = false;     // leaf fronts with m <= 16: 16-lanes-per-front kernels
     bool inv = false;      // large fronts on the inverse-based path (W_j = L_jj^{-1} in the arena, pivots in dvec)
 };
@@ -56,6 +57,7 @@ class MfSolver {
     bool factored_inv = false;
 
    private:
+    void launch_big_assemble(const MfLaunch& L, dim3 grid, const double* d_values, hipStream_t st);
     void forward_pass(const double* d_b_np1, hipStream_t st, StageTimers* timers);
     void backward_pass(double* d_x_np1, hipStream_t st, StageTimers* timers);
     DevBuf<double> d_bx, d_xx, d_one;     // bordered right-hand side / solution of solve(), the constant 1
