@@ -508,8 +508,12 @@ def newton(F0, F1, F2, x, maxit=10000, stopping_criterion=None, line_search=None
         if stats is not None:
             stats["solve_s"] = stats.get("solve_s", 0.0) + time.perf_counter() - t0
             stats["newton_its"] = stats.get("newton_its", 0) + 1
+            if "y_hist" in stats:                       # objective before this iteration (test instrumentation)
+                stats["y_hist"].append(y)
             if "deadline" in stats and time.perf_counter() > stats["deadline"]:
                 raise TimeoutError("oracle time budget exhausted")
+            if "max_its" in stats and stats["newton_its"] >= stats["max_its"]:
+                raise TimeoutError("oracle iteration budget exhausted")
         if not np.all(np.isfinite(n)):
             raise FloatingPointError("newton: Newton direction has non-finite entries")
         inc = float(np.dot(g, n))
