@@ -321,13 +321,25 @@ __global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
     double* opL = zl + 256 * nu;                        // [nstage][EPB][PP]
     double* YL = opL + (size_t)Pm.nstage * EPB * PP;    // [EPB][NT][G]
 
-    {
+    {   // operator blocks of this workgroup's elements -> LDS.  All loads of a stage are issued before the first
+        // LDS store (a rolled copy loop waits one memory latency per iteration)
         int64_t lim = (Pm.N - e0) * PP;
         if (lim > (int64_t)EPB * PP) lim = (int64_t)EPB * PP;
+        constexpr int NIT = (EPB * PP + 255) / 256;
         for (int o = 0; o < Pm.nstage; ++o) {
             const double* src = Pm.stage_ptr[o] + e0 * PP;
             double* dst = opL + (size_t)o * EPB * PP;
-            for (int i = tid; i < lim; i += 256) dst[i] = src[i];
+            double v[NIT];
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int i = tid + 256 * u;
+                v[u] = i < lim ? src[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int i = tid + 256 * u;
+                if (i < lim) dst[i] = v[u];
+            }
         }
     }
     if (active) {
@@ -478,13 +490,25 @@ __global__ __launch_bounds__(256) void elem_f01_fast(const ElemParams Pm) {
     double* zl = sh;                                    // [EPB][nu][G]
     double* opL = zl + 256 * nu;                        // [nstage][EPB][PP]
     double* YL = opL + (size_t)Pm.nstage * EPB * PP;    // [EPB][NY][G]
-    {
+    {   // operator blocks of this workgroup's elements -> LDS.  All loads of a stage are issued before the first
+        // LDS store (a rolled copy loop waits one memory latency per iteration)
         int64_t lim = (Pm.N - e0) * PP;
         if (lim > (int64_t)EPB * PP) lim = (int64_t)EPB * PP;
+        constexpr int NIT = (EPB * PP + 255) / 256;
         for (int o = 0; o < Pm.nstage; ++o) {
             const double* src = Pm.stage_ptr[o] + e0 * PP;
             double* dst = opL + (size_t)o * EPB * PP;
-            for (int i = tid; i < lim; i += 256) dst[i] = src[i];
+            double v[NIT];
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int i = tid + 256 * u;
+                v[u] = i < lim ? src[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int i = tid + 256 * u;
+                if (i < lim) dst[i] = v[u];
+            }
         }
     }
     // the node's cost row and weights do not depend on anything staged: request them with the operators
