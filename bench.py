@@ -245,6 +245,9 @@ def main():
         measured_frac=(gbs(traffic, avg_us["f2"]) / HBM_PEAK_GBS if traffic else None),
         aggregate=dict(stages_us={"f0+f1 (one pass)": trial_us, "restrict": avg_us["restrict"], "f2": avg_us["f2"],
                                   "assemble": avg_us["assemble"]}, total_us=agg_us,
+                       note=("bytes are SURVEY 8(d)'s algorithmic 1285 B/node; the device moves fewer: the trial reads the operators "
+                             "once for f0 and f1, and the fine level never forms H as a CSR value array (the factorization reads "
+                             "single-contribution entries from the element-block slab, 'assemble' sums only the shared ones)"),
                        bytes=sum(BYTES.values()) * n, gbs=gbs(sum(BYTES.values()) * n, agg_us),
                        frac=gbs(sum(BYTES.values()) * n, agg_us) / HBM_PEAK_GBS),
         factor_avg_us=avg_us["factor"], trisolve_avg_us=avg_us["trisolve"],

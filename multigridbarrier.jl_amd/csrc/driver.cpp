@@ -72,7 +72,7 @@ struct NewtonCtx {
     int64_t m;
     double F0(const double* d_s) { return P->eval_f0(level, d_s, d_zJ, d_c); }
     void F1(const double* d_s, double* d_out) { P->eval_f1(level, d_s, d_zJ, d_c, d_out); }
-    void F2(const double* d_s) { P->eval_f2(level, d_s, d_zJ, d_c); }
+    void F2(const double* d_s) { P->eval_f2(level, d_s, d_zJ, d_c, false); }   // H stays in the slab where the level allows
 };
 
 // One line-search trial shared by both searches: evaluates F0/F1 at xn (already formed in

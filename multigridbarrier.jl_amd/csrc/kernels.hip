@@ -776,6 +776,26 @@ __global__ __launch_bounds__(256) void gather_assemble_kernel(int64_t nnz, const
     Hval[q] = s;
 }
 
+// Direct-value levels: only the structural nonzeros shared between elements are summed (into a compact array
+// behind the slab); the single-contribution ones are read from the slab by the factorization itself.
+__global__ __launch_bounds__(256) void gather_shared_kernel(int64_t nshared, const int32_t* __restrict__ sh_q,
+                                                            const int32_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
+                                                            const double* __restrict__ slab, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nshared) return;
+    const int32_t q = sh_q[i];
+    const int32_t beg = cptr[q], end = cptr[q + 1];
+    double s = 0.0;
+    for (int32_t t = beg; t < end; t += 4) {                 // four contributions in flight, added in list order
+        double a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = (t + u < end) ? slab[cidx[t + u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += a[u];
+    }
+    out[i] = s;
+}
+
 // Long contribution lists (coarse levels: few unknowns, every element contributes): one wave per
 // structural nonzero, lanes stride over the list, fixed-order shuffle reduction.
 __global__ __launch_bounds__(256) void gather_assemble_wave_kernel(int64_t nnz, const int32_t* __restrict__ cptr,
@@ -1352,6 +1372,14 @@ void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cid
     else
         hipLaunchKernelGGL(gather_assemble_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, cptr,
                            cidx, slab, Hval);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_gather_shared(int64_t nshared, const int32_t* sh_q, const int32_t* cptr, const int32_t* cidx, const double* slab,
+                          double* out, hipStream_t st) {
+    if (nshared == 0) return;
+    hipLaunchKernelGGL(gather_shared_kernel, dim3((unsigned)((nshared + 255) / 256)), dim3(256), 0, st, nshared, sh_q, cptr, cidx,
+                       slab, out);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

@@ -78,6 +78,9 @@ void launch_axpy(double alpha, const double* x, double* y, int64_t len, hipStrea
 void launch_fill(double value, double* y, int64_t len, hipStream_t st);       // y[:] = value
 
 // selection levels: H[q] = sum_{t in contributions(q)} slab[cidx[t]]
+// sums of the structural nonzeros with other than one contribution (direct-value levels), in list order
+void launch_gather_shared(int64_t nshared, const int32_t* sh_q, const int32_t* cptr, const int32_t* cidx, const double* slab,
+                          double* out, hipStream_t st);
 void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,
                             double* Hval, bool long_lists, hipStream_t st, int32_t chunk = 0, int32_t nchunk = 0,
                             double* part = nullptr);     // nchunk > 1: two-stage sums of very long lists

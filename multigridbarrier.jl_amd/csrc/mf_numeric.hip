@@ -2104,17 +2104,31 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
 static StageTimers g_dummy_timers;
 static StageTimers* timers_or_dummy(StageTimers* t, bool on) { return (t && on) ? t : &g_dummy_timers; }
 
-void MfSolver::launch_big_assemble(const MfLaunch& L, dim3 ga, const double* d_values, hipStream_t st) {
+void MfSolver::launch_big_assemble(const MfLaunch& L, dim3 ga, const double* d_values, const int32_t* a_src_p, hipStream_t st) {
     const size_t lds = (size_t)L.max_child * (size_t)L.max_m * sizeof(int32_t);
     if (L.max_child >= 1 && L.max_child <= GATHER_MAX_CHILD && lds <= 60 * 1024)
-        hipLaunchKernelGGL(mf_big_gather, ga, dim3(256), lds, st, d_fronts.p, L.first, d_children.p, d_rel.p, d_a_src.p,
+        hipLaunchKernelGGL(mf_big_gather, ga, dim3(256), lds, st, d_fronts.p, L.first, d_children.p, d_rel.p, a_src_p,
                            d_a_dst.p, d_a_colptr.p, d_values, d_arena.p, L.max_m);
     else
-        hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p, d_a_src.p,
+        hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p, a_src_p,
                            d_a_dst.p, d_a_colptr.p, d_values, d_arena.p);
 }
 
-void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timers) {
+void MfSolver::set_direct_map(const int32_t* value_map, int64_t nnz, int64_t tail_base, hipStream_t st) {
+    std::vector<int32_t> as(plan.a_src.size());
+    for (size_t t = 0; t < as.size(); ++t) {
+        const int64_t src = plan.a_src[t];
+        const int64_t v = src < nnz ? (int64_t)value_map[src] : tail_base + (src - nnz);
+        MGB_REQUIRE(v < (int64_t)INT32_MAX, "direct value index exceeds 32 bits");
+        as[t] = (int32_t)v;
+    }
+    d_a_src_direct.upload(as, st);
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timers, bool direct) {
+    MGB_REQUIRE(!direct || d_a_src_direct.n > 0, "MfSolver::factor: no direct value map");
+    const int32_t* a_src_p = direct ? d_a_src_direct.p : d_a_src.p;
     MGB_REQUIRE(analyzed, "MfSolver::factor before analyze");
     if (timers) timers->begin("factor");
     factored_inv = !robust;
@@ -2130,7 +2144,7 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
             if (L.count == 0) continue;
             if (L.tiny) {
                 hipLaunchKernelGGL(mf_factor_tiny, dim3((L.count + 15) / 16), dim3(256), 0, st, d_fronts.p, L.first,
-                                   L.count, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                                   L.count, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
             } else if (L.cls) {
                 static const int nbt_mid = [] { const char* e = getenv("MGBHIP_NBT"); return e ? atoi(e) : 8; }();
                 static const int thr_mid = [] { const char* e = getenv("MGBHIP_SMALL_THREADS"); return e ? atoi(e) : 256; }();
@@ -2140,16 +2154,16 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 const size_t lds = (size_t)(L.cls * L.cls + nbt_alloc * L.cls) * sizeof(double);    // front + scaled panel
                 if (nbt <= 8)
                     hipLaunchKernelGGL(mf_factor_small<8>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                                       d_children.p, d_rel.p, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
                 else if (nbt <= 16)
                     hipLaunchKernelGGL(mf_factor_small<16>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                                       d_children.p, d_rel.p, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
                 else
                     hipLaunchKernelGGL(mf_factor_small<32>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, d_a_src.p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                                       d_children.p, d_rel.p, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
             } else if (L.inv && !robust) {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
-                launch_big_assemble(L, ga, d_values, st);
+                launch_big_assemble(L, ga, d_values, a_src_p, st);
                 // many fronts: factor block 0 once per front up front instead of inside every tile of step 0
                 const bool pre_diag = L.count >= 24;
                 if (pre_diag)
@@ -2164,7 +2178,7 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 }
             } else {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
-                launch_big_assemble(L, ga, d_values, st);
+                launch_big_assemble(L, ga, d_values, a_src_p, st);
                 for (int j0 = 0; j0 < L.max_k; j0 += NB) {
                     const int rem = L.max_m - j0;                // rows from the panel start, at most
                     const dim3 gp(std::max(1, (rem - 1 + TR - 1) / TR), L.count);

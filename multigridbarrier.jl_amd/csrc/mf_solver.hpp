@@ -33,7 +33,11 @@ class MfSolver {
                  const double* coords = nullptr, int dim = 0);
     // factor the matrix whose CSR values (same pattern as analyze) live at d_values.
     // Asynchronous; the not-SPD flag is read back by status().
-    void factor(const double* d_values, hipStream_t st, StageTimers* timers);
+    // direct = true: d_values is the value space of set_direct_map (slab | shared | border) instead of the CSR array
+    void factor(const double* d_values, hipStream_t st, StageTimers* timers, bool direct = false);
+    // Second scatter list for the same plan: CSR position q -> value_map[q], border entry v -> tail_base + v.
+    void set_direct_map(const int32_t* value_map, int64_t nnz, int64_t tail_base, hipStream_t st);
+    bool has_direct_map() const { return d_a_src_direct.n > 0; }
     // Every system is factored BORDERED, [H c; c' gamma] (MfOptions::border): the value array passed to factor()
     // carries the border column in its tail, d_values[nnz + v] = c_v (v < n) and d_values[nnz + n] = gamma.
     //   c = 0, gamma = 1:  block diagonal; solve() is the ordinary forward + backward sweep of H x = b.
@@ -57,12 +61,12 @@ class MfSolver {
     bool factored_inv = false;
 
    private:
-    void launch_big_assemble(const MfLaunch& L, dim3 grid, const double* d_values, hipStream_t st);
+    void launch_big_assemble(const MfLaunch& L, dim3 grid, const double* d_values, const int32_t* a_src_p, hipStream_t st);
     void forward_pass(const double* d_b_np1, hipStream_t st, StageTimers* timers);
     void backward_pass(double* d_x_np1, hipStream_t st, StageTimers* timers);
     DevBuf<double> d_bx, d_xx, d_one;     // bordered right-hand side / solution of solve(), the constant 1
     DevBuf<FrontDev> d_fronts;
-    DevBuf<int32_t> d_front_idx, d_children, d_rel, d_a_src, d_a_dst, d_a_colptr;
+    DevBuf<int32_t> d_front_idx, d_children, d_rel, d_a_src, d_a_src_direct, d_a_dst, d_a_colptr;
     DevBuf<int64_t> d_ug_ptr, d_ug_src;   // per large front: for every local index the children's update-vector entries, in child order
     DevBuf<double> d_arena, d_uvec, d_y, d_tbig, d_tsol, d_dscr, d_dvec;
     DevBuf<int32_t> d_status;

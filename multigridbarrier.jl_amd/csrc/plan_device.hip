@@ -129,6 +129,31 @@ __global__ void row_pointers(const uint64_t* __restrict__ keys, const uint64_t* 
     if (i == 0) cptr[nnz] = total;
 }
 
+// Direct-value map of a selection level: a structural nonzero with exactly one contribution IS an entry of
+// the element-block slab; the others (shared between elements, or empty) get a slot in a compact "shared" array
+// behind the slab.  vmap[q] = slab index, or extra_base + rank among the shared ones.
+__global__ void shared_flags(const int32_t* __restrict__ cptr, int64_t nnz, uint32_t* __restrict__ flag) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x)
+        flag[q] = (cptr[q + 1] - cptr[q] != 1) ? 1u : 0u;
+}
+
+__global__ void value_map(const int32_t* __restrict__ cptr, const int32_t* __restrict__ cidx, const uint32_t* __restrict__ flag,
+                          const uint32_t* __restrict__ rank, int64_t nnz, int32_t extra_base, int32_t* __restrict__ vmap,
+                          int32_t* __restrict__ sh_q) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x) {
+        if (flag[q]) {
+            vmap[q] = extra_base + (int32_t)rank[q];
+            sh_q[rank[q]] = (int32_t)q;
+        } else {
+            vmap[q] = cidx[cptr[q]];
+        }
+    }
+}
+
+struct PlusU32 {
+    __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; }
+};
+
 struct PlusU64 {
     __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return a + b; }
 };
@@ -214,6 +239,30 @@ void build_plan_device(const PlanDeviceIn& in, Level& L, hipStream_t st) {
     L.Hcol.download(L.hHcol.data(), (size_t)nnz, st);
     MGB_HIP_CHECK(hipStreamSynchronize(st));
     L.long_lists = nnz > 0 && total / nnz > 48;
+    // direct-value map (selection levels): lets the solver read single-contribution entries straight from the slab
+    L.direct = false;
+    if (in.selection && in.extra_base > 0 && nnz > 0 && in.extra_base + nnz + m + 1 < (int64_t)INT32_MAX) {
+        DevBuf<uint32_t> fl, rk;
+        DevBuf<int32_t> vmap;
+        fl.alloc((size_t)nnz); rk.alloc((size_t)nnz); vmap.alloc((size_t)nnz);
+        L.sh_q.alloc((size_t)nnz);          // upper bound; only the first nshared entries are used
+        const int64_t qb = std::min<int64_t>((nnz + 255) / 256, 1 << 16);
+        hipLaunchKernelGGL(shared_flags, dim3((unsigned)qb), dim3(256), 0, st, L.cptr.p, nnz, fl.p);
+        size_t sb = 0;
+        MGB_HIP_CHECK(rocprim::exclusive_scan(nullptr, sb, fl.p, rk.p, (uint32_t)0, (size_t)nnz, PlusU32(), st));
+        tmp.ensure(sb + 16);
+        MGB_HIP_CHECK(rocprim::exclusive_scan((void*)tmp.p, sb, fl.p, rk.p, (uint32_t)0, (size_t)nnz, PlusU32(), st));
+        hipLaunchKernelGGL(value_map, dim3((unsigned)qb), dim3(256), 0, st, L.cptr.p, L.cidx.p, fl.p, rk.p, nnz, (int32_t)in.extra_base,
+                           vmap.p, L.sh_q.p);
+        uint32_t lr = 0, lf = 0;
+        MGB_HIP_CHECK(hipMemcpyAsync(&lr, rk.p + (nnz - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        MGB_HIP_CHECK(hipMemcpyAsync(&lf, fl.p + (nnz - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        L.h_vmap.resize((size_t)nnz);
+        vmap.download(L.h_vmap.data(), (size_t)nnz, st);
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
+        L.nshared = (int64_t)lr + lf;
+        L.direct = true;
+    }
 }
 
 }  // namespace mgbhip

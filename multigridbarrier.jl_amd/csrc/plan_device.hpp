@@ -22,6 +22,8 @@ struct PlanDeviceIn {
     uint32_t state_id_mask;
     int32_t diag_mask_sel;
     int64_t sel_off[MGBHIP_MAX_NU * (MGBHIP_MAX_NU + 1) / 2];
+    // > 0: also build the direct-value map (Level::h_vmap, sh_q, nshared); slots of shared entries start here
+    int64_t extra_base;
 };
 
 // above this the transient sort buffers (about 40 B per pair) are not worth it: the host builder takes over

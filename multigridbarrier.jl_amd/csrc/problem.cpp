@@ -215,7 +215,8 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
         P->d_dnY.alloc((size_t)P->n * (P->nD * (P->nD + 1) / 2));
         P->d_hel.alloc(1);
     } else {
-        P->d_hel.alloc((size_t)P->N * hel_blocks(P->nu) * P->p * P->p);
+        P->hel_cap = (int64_t)P->N * hel_blocks(P->nu) * P->p * P->p;
+        P->d_hel.alloc((size_t)P->hel_cap);
     }
     P->d_partials.alloc((size_t)elem_grid(P->p, P->N));
     P->d_scal.alloc(16);
@@ -401,6 +402,8 @@ void mgbhip_problem::ensure_plan(int level) {
         in.diag_mask_sel = diag_mask_sel;
         for (int a = 0; a < nu; ++a) if (state_id[a]) in.state_id_mask |= 1u << a;
         hel_layout(nu, NE, pp, diag_mask_sel, in.sel_off);
+        static const bool no_direct = [] { const char* e = getenv("MGBHIP_NO_DIRECT"); return e && e[0] == '1'; }();
+        in.extra_base = (selection && !no_direct && hel_cap > 0) ? hel_cap : 0;
         if (!host_plan && plan_device_pairs(in) <= PLAN_DEVICE_MAX_PAIRS) {
             if (selection) {
                 in.Rptr = L.Rptr.p; in.Rcol = L.Rcol.p;
@@ -415,6 +418,10 @@ void mgbhip_problem::ensure_plan(int level) {
             }
             build_plan_device(in, L, st);
             device_plan = true;
+            if (L.direct) {          // room for the shared sums and the border column behind the slab
+                d_hel.ensure((size_t)(hel_cap + L.nshared + m + 1));
+                hel_level = -1;
+            }
         }
     }
     if (device_plan) {
@@ -714,7 +721,7 @@ void mgbhip_problem::eval_f01_launch(int level, const double* d_s, const double*
     cnt.f1++;
 }
 
-void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc) {
+void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc, bool materialize) {
     ensure_plan(level);
     hipStream_t st = stream();
     Level& L = levels[level];
@@ -744,6 +751,8 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
                 launch_dense_gemm_tn((int)L.m, (int)L.m, (int)((khi - klo + 1) * n), L.denseDR.p + (int64_t)klo * n, ld,
                                      nullptr, L.denseW.p + (int64_t)klo * n, ld, L.Hval.p, L.m, false, true, st);
             }
+        } else if (L.selection && L.direct && !materialize) {
+            launch_gather_shared(L.nshared, L.sh_q.p, L.cptr.p, L.cidx.p, d_hel.p, d_hel.p + hel_cap, st);
         } else if (L.selection) {
             launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, d_hel.p, L.Hval.p, L.long_lists, st, L.gather_chunk, L.gather_nchunk, L.gather_part.p);
         } else {
@@ -763,6 +772,8 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
         }
     }
     L.have_H = true;
+    L.H_in_slab = L.selection && L.direct && !materialize && !dense;
+    hel_level = L.H_in_slab ? level : -1;         // any f2 overwrites the slab
     L.factored = false;
     cnt.f2++;
 }
@@ -795,6 +806,24 @@ void mgbhip_problem::factor(int level, const double* rhs) {
             fprintf(stderr, "[mgbhip] symbolic analysis level %d (m=%lld, nnz=%lld): %.2f s\n", level, (long long)L.m,
                     (long long)L.nnz, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
+    if (L.H_in_slab) {
+        // H was not materialised (eval_f2 with materialize = false): the values are the slab + shared sums in d_hel
+        MGB_REQUIRE(hel_level == level, "the element blocks of this level's Hessian were overwritten: evaluate f2 again");
+        MGB_REQUIRE(rhs != nullptr, "a Hessian kept in the slab is factored together with its right-hand side");
+        if (!L.solver.has_direct_map()) {
+            L.solver.set_direct_map(L.h_vmap.data(), L.nnz, hel_cap + L.nshared, st);
+            std::vector<int32_t>().swap(L.h_vmap);        // 4 B per nonzero: not needed again
+        }
+        double* tail = d_hel.p + hel_cap + L.nshared;
+        launch_scale_copy(rhs, -1.0, tail, L.m, st);
+        launch_fill(-1.0, tail + L.m, 1, st);
+        L.solver.factor(d_hel.p, st, &ctx->timers, true);
+        L.border_state2 = 2;
+        L.factored = true;
+        cnt.factor++;
+        return;
+    }
+    L.border_state2 = 0;
     if (rhs) {          // border column -g, corner -1: the factorization carries the forward substitution of H x = g
         launch_scale_copy(rhs, -1.0, L.Hval.p + L.nnz, L.m, st);
         launch_fill(-1.0, L.Hval.p + L.nnz + L.m, 1, st);
@@ -812,12 +841,12 @@ void mgbhip_problem::factor(int level, const double* rhs) {
 void mgbhip_problem::trisolve(int level, const double* d_g, double* d_xout) {
     Level& L = levels[level];
     MGB_REQUIRE(L.factored, "triangular solve before factorization");
-    MGB_REQUIRE(L.border_state == 1, "triangular solve on factors that carry a Newton right-hand side");
+    MGB_REQUIRE(L.border_state == 1 && L.border_state2 == 0, "triangular solve on factors that carry a Newton right-hand side");
     L.solver.solve(d_g, d_xout, stream(), &ctx->timers);
 }
 
 void mgbhip_problem::trisolve_carried(int level, double* d_xout_np1) {
     Level& L = levels[level];
-    MGB_REQUIRE(L.factored && L.border_state == 2, "carried solve without a factorization that carries the right-hand side");
+    MGB_REQUIRE(L.factored && (L.border_state == 2 || L.border_state2 == 2), "carried solve without a factorization that carries the right-hand side");
     L.solver.solve_border(d_xout_np1, stream(), &ctx->timers);
 }

@@ -61,6 +61,14 @@ struct Level {
     DevBuf<double> denseDR, denseW;
     MfSolver solver;
     bool have_H = false, factored = false;
+    // direct values (fine / selection levels): the solver reads single-contribution entries of H straight from the
+    // element-block slab d_hel and the shared ones from a compact array behind it: no CSR value array is formed
+    bool direct = false;
+    int64_t nshared = 0;
+    DevBuf<int32_t> sh_q;                 // CSR positions of the shared entries
+    std::vector<int32_t> h_vmap;          // CSR position -> index into [slab | shared | border]
+    bool H_in_slab = false;               // the last eval_f2 of this level left H in d_hel (not in Hval)
+    int border_state2 = 0;                // 2: the current factors came from the slab path with a Newton right-hand side
     int border_state = 0;                 // tail of Hval: 0 unset, 1 identity border (solve), 2 Newton right-hand side (solve_border)
 };
 
@@ -113,7 +121,11 @@ struct mgbhip_problem {
     void eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
     // one line-search trial: f0 (value in d_scal[0]) and f1 (gradient in d_gout) from one sweep over the elements
     void eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
-    void eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc);
+    // materialize = false (Newton loop): on direct levels only the shared entries are summed, H is not formed as a CSR
+    // value array and the next factor(level, rhs) reads the slab (valid until the next eval_f2 of any level)
+    void eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc, bool materialize = true);
+    int64_t hel_cap = 0;                   // doubles of the element-block slab region of d_hel; extras live behind it
+    int hel_level = -1;                    // level whose blocks + shared sums d_hel currently holds (direct mode), or -1
     // returns MGBHIP_OK or MGBHIP_ERR_NOT_SPD; x = H^{-1} g on the device
     // rhs == nullptr: factor H for ordinary solves (trisolve).  rhs = g: factor the bordered matrix [H -g; -g' -1],
     // which performs the forward substitution of H x = g inside the factorization; trisolve_carried then needs the
