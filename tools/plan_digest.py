@@ -39,6 +39,13 @@ def main():
             s = 1e-4 * np.random.default_rng(l).standard_normal(amg.R_fine[l].shape[1])
             out[f"{name}/{l}"] = digest(D.main.f2(l, s, c, z0))
         D.close()
+    if len(sys.argv) > 1 and sys.argv[1] == "solve":
+        # complete solves: the Newton loop keeps the fine Hessian in the slab (direct values) unless MGBHIP_NO_DIRECT=1
+        for name, make in (("fem2d_L4_p15", lambda: m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 4)), p=1.5)),
+                           ("fem1d_L5_p1", lambda: m.assemble(m.amg(m.subdivide(m.fem1d(), 5)), p=1.0))):
+            sol = m.mgb_solve(make())
+            h = hashlib.sha256(np.ascontiguousarray(sol.z, dtype=np.float64).tobytes()).hexdigest()
+            out[f"solve/{name}"] = [h, [int(v) for v in np.asarray(sol.SOL_main["its"]).ravel()]]
     print(json.dumps(out))
 
 
