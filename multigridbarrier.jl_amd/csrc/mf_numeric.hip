@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void mf_factor_tiny(const FrontDev* __restrict
                                                       const int32_t* __restrict__ a_dst,
                                                       const double* __restrict__ Hval, double* __restrict__ arena,
                                                       int32_t* __restrict__ status) {
-    __shared__ double Wt[16][256];
+    __shared__ double Wt[16][136];          // packed lower triangle, column stride 16 (a_dst is remapped by analyze())
     __shared__ double colb[16][16];
     const int g = threadIdx.x >> 4, r = threadIdx.x & 15;
     const int fi = blockIdx.x * 16 + g;
@@ -1018,14 +1018,14 @@ __global__ __launch_bounds__(256) void mf_factor_tiny(const FrontDev* __restrict
     const FrontDev F = fr[first + (on ? fi : 0)];
     const int m = F.m, k = on ? F.k : 0;
     double* W = Wt[g];
-    for (int i = r; i < 256; i += 16) W[i] = 0.0;
+    for (int i = r; i < 136; i += 16) W[i] = 0.0;
     wave_sync();
     if (on)
         for (int t = r; t < F.a_cnt; t += 16) W[a_dst[F.a_off + t]] = Hval[a_src[F.a_off + t]];
     wave_sync();
     double a[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = (on && r < m && c <= r) ? W[r + c * m] : 0.0;
+    for (int c = 0; c < 16; ++c) a[c] = (on && r < m && c <= r) ? W[c * 16 - c * (c - 1) / 2 + (r - c)] : 0.0;
     int kmax = k;
     kmax = max(kmax, __shfl_xor(kmax, 16, 64));
     kmax = max(kmax, __shfl_xor(kmax, 32, 64));
@@ -1981,7 +1981,21 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     d_children.upload(plan.children, st);
     d_rel.upload(plan.rel, st);
     d_a_src.upload(plan.a_src, st);
-    d_a_dst.upload(plan.a_dst, st);
+    {   // leaf fronts with m <= 16 (mf_factor_tiny) scatter A into a PACKED lower triangle with column stride 16:
+        // 136 LDS doubles per front instead of 256, which doubles the resident workgroups of that kernel
+        std::vector<int32_t> ad(plan.a_dst);
+        if (plan.level_ptr.size() > 1)
+            for (int32_t i = plan.level_ptr[0]; i < plan.level_ptr[1]; ++i) {
+                const Front& f = plan.fronts[i];
+                if (f.m > 16) continue;
+                for (int32_t t = 0; t < f.a_cnt; ++t) {
+                    const int32_t d = plan.a_dst[f.a_off + t], lu = d % f.m, lv = d / f.m;      // row lu >= column lv
+                    ad[f.a_off + t] = lv * 16 - lv * (lv - 1) / 2 + (lu - lv);
+                }
+            }
+        d_a_dst.upload(ad, st);
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
+    }
     d_a_colptr.upload(plan.a_colptr, st);
     d_arena.alloc((size_t)std::max<int64_t>(plan.arena_doubles, 1));
     d_uvec.alloc((size_t)std::max<int64_t>(plan.uvec_doubles, 1));
