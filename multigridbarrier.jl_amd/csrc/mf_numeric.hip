@@ -352,6 +352,141 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     SP(4);
 }
 
+// Fronts with m <= MW (32 or 48): ONE WAVE per front, no workgroup barriers.  The front is assembled in a packed
+// LDS triangle (column stride MW; analyze() remaps a_dst for these fronts), lane r then takes row r into
+// registers and the whole partial factorization -- k pivots and the Schur complement of the boundary rows -- is
+// wave_ldlt_regs: v_readlane broadcasts and FMAs only.  A 46-row front with 21 pivots and 16 leaf children takes
+// about half the time of the workgroup-per-front kernel, and twice as many fronts are resident per compute unit.
+template <int MW>
+__global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict__ fr, int32_t first, int32_t count,
+                                                      const int32_t* __restrict__ children, const int32_t* __restrict__ rel,
+                                                      const int32_t* __restrict__ a_src, const int32_t* __restrict__ a_dst,
+                                                      const double* __restrict__ Hval, double* __restrict__ arena,
+                                                      int32_t* __restrict__ status) {
+    constexpr int PK = MW * (MW + 1) / 2;
+    extern __shared__ double sh[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fi = blockIdx.x * 4 + wave;
+    if (fi >= count) return;                       // waves are independent: no workgroup barrier below
+    const FrontDev F = fr[first + fi];
+    const int m = F.m, k = F.k;
+    double* W = sh + (size_t)wave * PK;
+    // child descriptors of this wave (chunks of 64), behind the four fronts
+    int64_t* cU = reinterpret_cast<int64_t*>(sh + (size_t)4 * PK) + wave * 128;
+    int64_t* cR = cU + 64;
+    int32_t* cM = reinterpret_cast<int32_t*>(reinterpret_cast<int64_t*>(sh + (size_t)4 * PK) + 4 * 128) + wave * 128;
+    int32_t* cB = cM + 64;
+    auto pidx = [](int r, int c) { return c * MW - c * (c - 1) / 2 + (r - c); };
+    // first batch of A entries and the first chunk of child descriptors are requested before the triangle is zeroed
+    int a_d0 = -1;
+    double a_v0 = 0.0;
+    if (lane < F.a_cnt) {
+        a_d0 = a_dst[F.a_off + lane];
+        a_v0 = Hval[a_src[F.a_off + lane]];
+    }
+    int64_t pU = 0, pR = 0;
+    int32_t pM = 0, pB = 0;
+    if (lane < min(64, F.nchild)) {
+        const FrontDev C = fr[children[F.child_off + lane]];
+        pU = C.F_off + (int64_t)C.k * C.m + C.k;
+        pR = C.rel_off;
+        pM = C.m;
+        pB = C.m - C.k;
+    }
+    for (int i = lane; i < PK; i += 64) W[i] = 0.0;
+    wave_sync();
+    if (a_d0 >= 0) W[a_d0] = a_v0;
+    for (int t = lane + 64; t < F.a_cnt; t += 64) W[a_dst[F.a_off + t]] = Hval[a_src[F.a_off + t]];
+    wave_sync();
+    for (int cbase = 0; cbase < F.nchild; cbase += 64) {
+        const int nc = min(64, F.nchild - cbase);
+        if (lane < nc) {
+            if (cbase == 0) {
+                cU[lane] = pU; cR[lane] = pR; cM[lane] = pM; cB[lane] = pB;
+            } else {
+                const FrontDev C = fr[children[F.child_off + cbase + lane]];
+                cU[lane] = C.F_off + (int64_t)C.k * C.m + C.k;
+                cR[lane] = C.rel_off;
+                cM[lane] = C.m;
+                cB[lane] = C.m - C.k;
+            }
+        }
+        wave_sync();
+        for (int c0 = 0; c0 < nc; c0 += 8) {
+            const int ng = min(8, nc - c0);
+            bool small8 = true;
+            for (int u = 0; u < ng; ++u) small8 = small8 && cB[c0 + u] * cB[c0 + u] <= 64;
+            if (small8) {
+                // eight small children: one entry per lane and child, all loads in flight, then added in child order
+                int dst[8];
+                double val[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    dst[u] = -1;
+                    val[u] = 0.0;
+                    if (u < ng) {
+                        const int c = c0 + u, b = cB[c];
+                        if (lane < b * b) {
+                            const int j = lane / b, r = lane - j * b;
+                            if (r >= j) {
+                                const int32_t* rl = rel + cR[c];
+                                dst[u] = pidx(rl[r], rl[j]);
+                                val[u] = arena[cU[c] + (int64_t)j * cM[c] + r];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (u < ng) {
+                        if (dst[u] >= 0) W[dst[u]] += val[u];
+                        wave_sync();                    // child u's stores before child u+1's loads
+                    }
+                }
+            } else {
+                for (int u = 0; u < ng; ++u) {
+                    const int c = c0 + u, b = cB[c], mc = cM[c];
+                    const int32_t* rl = rel + cR[c];
+                    const double* U = arena + cU[c];
+                    for (int e = lane; e < b * b; e += 256) {       // four entries per lane in flight
+                        int dd[4];
+                        double vv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int ee = e + 64 * q;
+                            dd[q] = -1;
+                            vv[q] = 0.0;
+                            if (ee < b * b) {
+                                const int j = ee / b, r = ee - j * b;
+                                if (r >= j) {
+                                    dd[q] = pidx(rl[r], rl[j]);
+                                    vv[q] = U[(int64_t)j * mc + r];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (dd[q] >= 0) W[dd[q]] += vv[q];         // distinct slots within one child
+                    }
+                    wave_sync();
+                }
+            }
+        }
+        wave_sync();
+    }
+    double a[MW];
+#pragma unroll
+    for (int c = 0; c < MW; ++c) a[c] = (lane < m && c <= lane) ? W[pidx(lane, c)] : 0.0;
+    const bool bad = wave_ldlt_regs<MW>(a, k, lane);
+    if (bad) atomicOr(status, 1);
+    if (lane < m) {
+        double* Fg = arena + F.F_off;
+#pragma unroll
+        for (int c = 0; c < MW; ++c)
+            if (c <= lane) Fg[lane + (int64_t)c * m] = a[c];
+    }
+}
+
 // Triangular solves of small fronts: one wave per front (4 fronts per workgroup), the work
 // vector lives in registers (rows lane and lane + 64), no workgroup barriers.
 __global__ __launch_bounds__(256) void mf_forward_small(const FrontDev* __restrict__ fr, int32_t first,
@@ -1981,21 +2116,6 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     d_children.upload(plan.children, st);
     d_rel.upload(plan.rel, st);
     d_a_src.upload(plan.a_src, st);
-    {   // leaf fronts with m <= 16 (mf_factor_tiny) scatter A into a PACKED lower triangle with column stride 16:
-        // 136 LDS doubles per front instead of 256, which doubles the resident workgroups of that kernel
-        std::vector<int32_t> ad(plan.a_dst);
-        if (plan.level_ptr.size() > 1)
-            for (int32_t i = plan.level_ptr[0]; i < plan.level_ptr[1]; ++i) {
-                const Front& f = plan.fronts[i];
-                if (f.m > 16) continue;
-                for (int32_t t = 0; t < f.a_cnt; ++t) {
-                    const int32_t d = plan.a_dst[f.a_off + t], lu = d % f.m, lv = d / f.m;      // row lu >= column lv
-                    ad[f.a_off + t] = lv * 16 - lv * (lv - 1) / 2 + (lu - lv);
-                }
-            }
-        d_a_dst.upload(ad, st);
-        MGB_HIP_CHECK(hipStreamSynchronize(st));
-    }
     d_a_colptr.upload(plan.a_colptr, st);
     d_arena.alloc((size_t)std::max<int64_t>(plan.arena_doubles, 1));
     d_uvec.alloc((size_t)std::max<int64_t>(plan.uvec_doubles, 1));
@@ -2073,6 +2193,41 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             level_launches[l].push_back(L);
             i = j;
         }
+    }
+    {   // Packed LDS triangles.  Leaf fronts with m <= 16 (mf_factor_tiny) scatter A with column stride 16: 136 LDS
+        // doubles per front instead of 256, which doubles the resident workgroups of that kernel.  Launches of fronts
+        // with m <= 48 whose children are all small (update block <= 8 x 8: the element leaves under a level-1
+        // front, or no children) go to the one-wave-per-front kernel mf_factor_wave, packed with stride 32 or 48;
+        // with large children the 256-thread kernel's extend-add is faster and the launch stays there.
+        std::vector<int32_t> ad(plan.a_dst);
+        static const bool no_wave = [] { const char* e = getenv("MGBHIP_NO_WAVE_SMALL"); return e && e[0] == '1'; }();
+        for (int32_t l = 0; l < nlev; ++l)
+            for (auto& L : level_launches[l]) {
+                int stride = 0;
+                if (L.tiny) stride = 16;
+                else if (L.cls && L.cls <= 48 && !no_wave) {
+                    bool ok = true;
+                    for (int32_t q = L.first; q < L.first + L.count && ok; ++q) {
+                        const Front& f = plan.fronts[q];
+                        for (int32_t c = 0; c < f.nchild && ok; ++c) {
+                            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
+                            ok = (ch.m - ch.k) * (ch.m - ch.k) <= 64;
+                        }
+                    }
+                    L.wave = ok;
+                    if (ok) stride = L.cls <= 32 ? 32 : 48;
+                }
+                if (!stride) continue;
+                for (int32_t q = L.first; q < L.first + L.count; ++q) {
+                    const Front& f = plan.fronts[q];
+                    for (int32_t t = 0; t < f.a_cnt; ++t) {
+                        const int32_t d = plan.a_dst[f.a_off + t], lu = d % f.m, lv = d / f.m;      // row lu >= column lv
+                        ad[f.a_off + t] = lv * stride - lv * (lv - 1) / 2 + (lu - lv);
+                    }
+                }
+            }
+        d_a_dst.upload(ad, st);
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
     }
     // the wave-per-front solve kernels do not depend on the LDS class: one launch per level
     level_solves.assign(nlev, {});
@@ -2159,6 +2314,17 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
             if (L.tiny) {
                 hipLaunchKernelGGL(mf_factor_tiny, dim3((L.count + 15) / 16), dim3(256), 0, st, d_fronts.p, L.first,
                                    L.count, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+            } else if (L.wave) {
+                const dim3 gw((L.count + 3) / 4);
+                if (L.cls <= 32) {
+                    const size_t lds = (size_t)4 * (32 * 33 / 2) * sizeof(double) + 4 * 128 * (sizeof(int64_t) + sizeof(int32_t));
+                    hipLaunchKernelGGL(mf_factor_wave<32>, gw, dim3(256), lds, st, d_fronts.p, L.first, L.count, d_children.p, d_rel.p,
+                                       a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                } else {
+                    const size_t lds = (size_t)4 * (48 * 49 / 2) * sizeof(double) + 4 * 128 * (sizeof(int64_t) + sizeof(int32_t));
+                    hipLaunchKernelGGL(mf_factor_wave<48>, gw, dim3(256), lds, st, d_fronts.p, L.first, L.count, d_children.p, d_rel.p,
+                                       a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                }
             } else if (L.cls) {
                 static const int nbt_mid = [] { const char* e = getenv("MGBHIP_NBT"); return e ? atoi(e) : 8; }();
                 static const int thr_mid = [] { const char* e = getenv("MGBHIP_SMALL_THREADS"); return e ? atoi(e) : 256; }();

@@ -22,6 +22,7 @@ struct MfLaunch {          // one kernel launch: a contiguous range of fronts of
     int32_t max_m, max_k;  // largest front / pivot block in the range
     int32_t max_child = 0; // most children of a front in the range
     bool tiny = false;     // leaf fronts with m <= 16: 16-lanes-per-front kernels
+    bool wave = false;     // m <= 48 and only small children: one wave per front (mf_factor_wave), packed LDS triangle
     bool inv = false;      // large fronts on the inverse-based path (W_j = L_jj^{-1} in the arena, pivots in dvec)
 };
 
