@@ -108,7 +108,7 @@ __device__ __forceinline__ bool wave_ldlt_regs(double (&a)[NBT], int nb, int lan
 // One workgroup per front.  Right-looking LDL' blocked by NB = 32 columns: wave 0 factors the
 // diagonal block in registers (shuffles only), every thread then solves one panel row in
 // registers, and all threads apply the rank-32 update -- 3 workgroup barriers per 32 columns.
-template <int NBT>
+template <int NBT, bool PACKED>
 __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                                 const int32_t* __restrict__ children, const int32_t* __restrict__ rel,
                                 const int32_t* __restrict__ a_src, const int32_t* __restrict__ a_dst,
@@ -120,7 +120,12 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     const int m = F.m, k = F.k;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int tx = tid % TX, ty = tid / TX, TYn = nt / TX;
-    const int mm = m * m;
+    // PACKED (classes 88 and 128, whose square arrays leave room for one or two workgroups per compute unit): the
+    // front lives in LDS as a packed lower triangle, column c at W + co(c) (entry (r, c), r >= c, at co(c) + r) --
+    // half the LDS, twice the resident fronts; analyze() remaps a_dst.  The smaller classes keep the square array
+    // (their occupancy is not LDS-bound and the plain column offset c * m is cheaper to form).
+    const int mm = PACKED ? m * (m + 1) / 2 : m * m;
+    auto co = [m](int c) { return PACKED ? c * (m - 1) - c * (c - 1) / 2 : c * m; };
     double* S = W + mm;                        // [NBT][m] scaled multipliers of the current panel
 
     SP(0);
@@ -197,7 +202,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                                 const int j = e / b, r = e - j * b;
                                 if (r >= j) {
                                     const int32_t* rl = rel + cR[c];
-                                    dst[u] = rl[r] + rl[j] * m;
+                                    dst[u] = rl[r] + co(rl[j]);
                                     val[u] = arena[cU[c] + (int64_t)j * cM[c] + r];
                                 }
                             }
@@ -233,7 +238,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                         const int j = tid / b, r = tid - j * b;
                         if (r >= j) {
                             const int32_t* rl = rel + cR[c];
-                            dst[u] = rl[r] + rl[j] * m;
+                            dst[u] = rl[r] + co(rl[j]);
                             val[u] = arena[cU[c] + (int64_t)j * cM[c] + r];
                         }
                     }
@@ -252,7 +257,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                     const double* U = arena + cU[c];
                     const int mc = cM[c];
                     for (int j = ty; j < b; j += TYn) {
-                        const int dcol = crl[j] * m;
+                        const int dcol = co(crl[j]);
                         const double* Uc = U + (int64_t)j * mc;
                         for (int r = j + tx; r < b; r += 4 * TX) {      // four rows per lane in flight
                             const int r1 = r + TX, r2 = r + 2 * TX, r3 = r + 3 * TX;
@@ -278,12 +283,12 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
         if (tid < 64) {                       // diagonal block in registers
             double a[NBT];
 #pragma unroll
-            for (int c = 0; c < NBT; ++c) a[c] = (tid < nb && c <= tid) ? W[(j0 + tid) + (j0 + c) * m] : 0.0;
+            for (int c = 0; c < NBT; ++c) a[c] = (tid < nb && c <= tid) ? W[(j0 + tid) + co(j0 + c)] : 0.0;
             bad |= wave_ldlt_regs<NBT>(a, nb, tid);
 #pragma unroll
             for (int c = 0; c < NBT; ++c)
                 if (tid < nb && c <= tid) {
-                    W[(j0 + tid) + (j0 + c) * m] = a[c];
+                    W[(j0 + tid) + co(j0 + c)] = a[c];
                     if (c == tid) prinv[c] = 1.0 / a[c];      // pivot reciprocals for the row solves
                 }
         }
@@ -293,14 +298,14 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
             if (r < m) {
                 double a[NBT];
 #pragma unroll
-                for (int c = 0; c < NBT; ++c) a[c] = (c < nb) ? W[r + (j0 + c) * m] : 0.0;
+                for (int c = 0; c < NBT; ++c) a[c] = (c < nb) ? W[r + co(j0 + c)] : 0.0;
 #pragma unroll
                 for (int c = 0; c < NBT; ++c) {
                     if (c < nb) {
                         double v = a[c];
 #pragma unroll
                         for (int q = 0; q < NBT; ++q)
-                            if (q < c) v -= a[q] * W[(j0 + c) + (j0 + q) * m];
+                            if (q < c) v -= a[q] * W[(j0 + c) + co(j0 + q)];
                         a[c] = v;
                     }
                 }
@@ -308,7 +313,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
 #pragma unroll
                 for (int c = 0; c < NBT; ++c) {
                     S[c * m + r] = (c < nb) ? a[c] : 0.0;
-                    if (c < nb) W[r + (j0 + c) * m] = a[c] * prinv[c];
+                    if (c < nb) W[r + co(j0 + c)] = a[c] * prinv[c];
                 }
             }
         }
@@ -334,12 +339,12 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                         double a1 = 0.0, a2 = 0.0;
 #pragma unroll
                         for (int q = 0; q < NBT; ++q) {
-                            const double l = (q < nb) ? W[ri + (j0 + q) * m] : 0.0;
+                            const double l = (q < nb) ? W[ri + co(j0 + q)] : 0.0;
                             a1 += l * s1[q];
                             a2 += l * s2[q];
                         }
-                        W[ri + c * m] -= a1;
-                        if (two && ri >= c2) W[ri + c2 * m] -= a2;
+                        W[ri + co(c)] -= a1;
+                        if (two && ri >= c2) W[ri + co(c2)] -= a2;
                     }
                 }
             }
@@ -348,7 +353,15 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     }
     SP(3);
     if (bad && tid == 0) atomicOr(status, 1);
-    for (int i = tid; i < mm; i += nt) Fg[i] = W[i];
+    // write the lower triangle back to the (square, column-major) frontal matrix: a 2-D sweep, rows fastest
+    if (PACKED) {
+        for (int c = ty; c < m; c += TYn) {
+            const int cc = co(c);
+            for (int r = c + tx; r < m; r += TX) Fg[r + (int64_t)c * m] = W[cc + r];
+        }
+    } else {
+        for (int i = tid; i < mm; i += nt) Fg[i] = W[i];
+    }
     SP(4);
 }
 
@@ -2135,11 +2148,11 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
 
     // dynamic LDS above 64 KB needs an explicit opt-in; fall back to the 64 KB classes if refused
     lds_cap = 88;
-    if (hipFuncSetAttribute((const void*)mf_factor_small<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)mf_factor_small<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (128 * 128 + 16 * 128) * 8) == hipSuccess &&
-        hipFuncSetAttribute((const void*)mf_factor_small<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)mf_factor_small<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (128 * 128 + 16 * 128) * 8) == hipSuccess &&
-        hipFuncSetAttribute((const void*)mf_factor_small<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)mf_factor_small<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (128 * 128 + 16 * 128) * 8) == hipSuccess)
         lds_cap = 128;
     else
@@ -2217,12 +2230,14 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
                     L.wave = ok;
                     if (ok) stride = L.cls <= 32 ? 32 : 48;
                 }
-                if (!stride) continue;
+                const bool lds_front = L.cls >= 88 && !stride;  // mf_factor_small, packed classes: the front's own m as stride
+                if (!stride && !lds_front) continue;
                 for (int32_t q = L.first; q < L.first + L.count; ++q) {
                     const Front& f = plan.fronts[q];
+                    const int32_t sd = lds_front ? f.m : stride;
                     for (int32_t t = 0; t < f.a_cnt; ++t) {
                         const int32_t d = plan.a_dst[f.a_off + t], lu = d % f.m, lv = d / f.m;      // row lu >= column lv
-                        ad[f.a_off + t] = lv * stride - lv * (lv - 1) / 2 + (lu - lv);
+                        ad[f.a_off + t] = lv * sd - lv * (lv - 1) / 2 + (lu - lv);
                     }
                 }
             }
@@ -2331,16 +2346,15 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 const int threads = L.cls <= 16 ? 64 : (L.cls <= 32 ? 128 : (L.cls <= 64 ? thr_mid : 256));
                 const int nbt = L.cls <= 16 ? 8 : std::min(nbt_mid, 16);    // 32-column LDS panels do not fit beside a 128 x 128 front
                 const int nbt_alloc = nbt <= 8 ? 8 : (nbt <= 16 ? 16 : 32);
-                const size_t lds = (size_t)(L.cls * L.cls + nbt_alloc * L.cls) * sizeof(double);    // front + scaled panel
-                if (nbt <= 8)
-                    hipLaunchKernelGGL(mf_factor_small<8>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
-                else if (nbt <= 16)
-                    hipLaunchKernelGGL(mf_factor_small<16>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
-                else
-                    hipLaunchKernelGGL(mf_factor_small<32>, dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first,
-                                       d_children.p, d_rel.p, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                const bool packed = L.cls >= 88;
+                const size_t lds = (size_t)((packed ? L.cls * (L.cls + 1) / 2 : L.cls * L.cls) + nbt_alloc * L.cls) * sizeof(double);    // front + scaled panel
+#define MGB_LAUNCH_SMALL(NBTV, PK)                                                                                          \
+    hipLaunchKernelGGL((mf_factor_small<NBTV, PK>), dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first, d_children.p, \
+                       d_rel.p, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p)
+                if (nbt <= 8) { if (packed) MGB_LAUNCH_SMALL(8, true); else MGB_LAUNCH_SMALL(8, false); }
+                else if (nbt <= 16) { if (packed) MGB_LAUNCH_SMALL(16, true); else MGB_LAUNCH_SMALL(16, false); }
+                else { if (packed) MGB_LAUNCH_SMALL(32, true); else MGB_LAUNCH_SMALL(32, false); }
+#undef MGB_LAUNCH_SMALL
             } else if (L.inv && !robust) {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
                 launch_big_assemble(L, ga, d_values, a_src_p, st);
