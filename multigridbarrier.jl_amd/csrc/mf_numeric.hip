@@ -617,88 +617,6 @@ __global__ __launch_bounds__(256) void mf_backward_small(const FrontDev* __restr
 // large fronts: batched multi-workgroup kernels (grid.y = front within the batch)
 // ------------------------------------------------------------------------------------------------
 
-// Gather form of the assembly for fronts with few children (every front of a nested-dissection tree above the
-// leaves has two to four): the inverse of every child's relative index list is laid out in LDS, then each
-// destination entry is formed ONCE in a register -- the children's entries that land on it, added in child order,
-// all their loads in flight together -- and stored once.  No zero pass, no read-modify-write of the arena, and
-// the dependent-load chains of the children run side by side instead of one child after the other.
-constexpr int GATHER_MAX_CHILD = 8;
-__global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict__ fr, int32_t first,
-                                                     const int32_t* __restrict__ children,
-                                                     const int32_t* __restrict__ rel,
-                                                     const int32_t* __restrict__ a_src,
-                                                     const int32_t* __restrict__ a_dst,
-                                                     const int32_t* __restrict__ a_colptr,
-                                                     const double* __restrict__ Hval, double* __restrict__ arena, int mstride) {
-    extern __shared__ int32_t inv[];               // [nchild][mstride]: position in the child's update block or -1
-    __shared__ int64_t cU[GATHER_MAX_CHILD];
-    __shared__ int64_t cR[GATHER_MAX_CHILD];
-    __shared__ int32_t cM[GATHER_MAX_CHILD], cB[GATHER_MAX_CHILD];
-    const FrontDev F = fr[first + blockIdx.y];
-    const int m = F.m;
-    const int c0 = blockIdx.x * CT;
-    if (c0 >= m) return;
-    const int c1 = min(c0 + CT, m);
-    double* W = arena + F.F_off;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;     // one wave per destination column, lanes on the rows
-    const int nch = F.nchild;
-    if (tid < nch) {
-        const FrontDev C = fr[children[F.child_off + tid]];
-        cU[tid] = C.F_off + (int64_t)C.k * C.m + C.k;
-        cR[tid] = C.rel_off;
-        cM[tid] = C.m;
-        cB[tid] = C.m - C.k;
-    }
-    for (int i = tid; i < nch * mstride; i += 256) inv[i] = -1;
-    __syncthreads();
-    for (int ch = 0; ch < nch; ++ch) {
-        const int32_t* rl = rel + cR[ch];
-        const int b = cB[ch];
-        for (int j = tid; j < b; j += 256) inv[ch * mstride + rl[j]] = j;
-    }
-    __syncthreads();
-    for (int c = c0 + wave; c < c1; c += 4) {
-        double* Wc = W + (int64_t)c * m;
-        int64_t colbase[GATHER_MAX_CHILD];         // child column offset, -1 when the child does not reach column c
-#pragma unroll
-        for (int ch = 0; ch < GATHER_MAX_CHILD; ++ch) {
-            const int jc = ch < nch ? inv[ch * mstride + c] : -1;
-            colbase[ch] = jc >= 0 ? cU[ch] + (int64_t)jc * cM[ch] : -1;
-        }
-        for (int r = c + lane; r < m; r += 128) {  // two rows per lane in flight
-            const int r1 = r + 64;
-            double u0[GATHER_MAX_CHILD], u1[GATHER_MAX_CHILD];
-#pragma unroll
-            for (int ch = 0; ch < GATHER_MAX_CHILD; ++ch) {
-                u0[ch] = 0.0;
-                u1[ch] = 0.0;
-                if (colbase[ch] >= 0) {
-                    const int i0 = inv[ch * mstride + r];
-                    const int i1 = r1 < m ? inv[ch * mstride + r1] : -1;
-                    if (i0 >= 0) u0[ch] = arena[colbase[ch] + i0];
-                    if (i1 >= 0) u1[ch] = arena[colbase[ch] + i1];
-                }
-            }
-            double v0 = 0.0, v1 = 0.0;
-#pragma unroll
-            for (int ch = 0; ch < GATHER_MAX_CHILD; ++ch) {      // child order: the summation order of the extend-add
-                v0 += u0[ch];
-                v1 += u1[ch];
-            }
-            Wc[r] = v0;
-            if (r1 < m) Wc[r1] = v1;
-        }
-    }
-    __syncthreads();
-    {   // A entries are grouped by pivot column: the per-column offsets give the range of [c0, c1)
-        const int32_t* cp = a_colptr + F.acol_off;
-        const int beg = cp[min(c0, F.k)], end = cp[min(c1, F.k)];
-        const int32_t* ad = a_dst + F.a_off;
-        for (int t = beg + tid; t < end; t += 256) W[ad[t]] += Hval[a_src[F.a_off + t]];
-    }
-}
-
 // Assembly of destination columns [c0, c0 + CT): zero, scatter A, extend-add the children.
 __global__ __launch_bounds__(256) void mf_big_assemble(const FrontDev* __restrict__ fr, int32_t first,
                                                        const int32_t* __restrict__ children,
@@ -1846,6 +1764,152 @@ __global__ __launch_bounds__(256) void mf_big_diag0(const FrontDev* __restrict__
     }
 }
 
+// Gather form of the assembly for fronts with few children (every front of a nested-dissection tree above the
+// leaves has two to four): the inverse of every child's relative index list is laid out in LDS, then each
+// destination entry is formed ONCE in a register -- the children's entries that land on it, added in child order,
+// all their loads in flight together -- and stored once.  No zero pass, no read-modify-write of the arena, and
+// the dependent-load chains of the children run side by side instead of one child after the other.
+constexpr int GATHER_MAX_CHILD = 8;
+__global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict__ fr, int32_t first,
+                                                     const int32_t* __restrict__ children,
+                                                     const int32_t* __restrict__ rel,
+                                                     const int32_t* __restrict__ a_src,
+                                                     const int32_t* __restrict__ a_dst,
+                                                     const int32_t* __restrict__ a_colptr,
+                                                     const double* __restrict__ Hval, double* __restrict__ arena, int mstride,
+                                                     double* __restrict__ dscr, int32_t* __restrict__ status, int with_diag) {
+    extern __shared__ int32_t inv[];               // [nchild][mstride]: position in the child's update block or -1
+    __shared__ int64_t cU[GATHER_MAX_CHILD];
+    __shared__ int64_t cR[GATHER_MAX_CHILD];
+    __shared__ int32_t cM[GATHER_MAX_CHILD], cB[GATHER_MAX_CHILD];
+    const FrontDev F = fr[first + blockIdx.y];
+    const int m = F.m;
+    if (with_diag && blockIdx.x == gridDim.x - 1) {
+        // One extra workgroup per front forms ONLY the first 32 x 32 diagonal block (same gather, same order as
+        // the column workgroups, which write it to the arena), factors and inverts it and leaves W_0 / d_0 in slot 0:
+        // step 0 of the factorization finds its diagonal block ready, as every later step does from the look-ahead
+        // workgroup.  Its time hides under the column workgroups of the same launch (was: a launch of its own for
+        // batches of many fronts, a redundant factorization inside every tile of step 0 for the others).
+        __shared__ double Wv[NB][NB + 1];
+        __shared__ double Dn[NB][NB + 1];
+        __shared__ double Tm[16][17];
+        __shared__ double dq[NB];
+        __shared__ __attribute__((aligned(16))) double colbuf[4 * NB];
+        __shared__ double Sp4[NB][4], Lp4[NB][4];
+        __shared__ int32_t inv0[GATHER_MAX_CHILD][NB];
+        const int tid = threadIdx.x, nch = F.nchild, nb = min(NB, F.k);
+        if (tid < nch) {
+            const FrontDev C = fr[children[F.child_off + tid]];
+            cU[tid] = C.F_off + (int64_t)C.k * C.m + C.k;
+            cR[tid] = C.rel_off;
+            cM[tid] = C.m;
+            cB[tid] = C.m - C.k;
+        }
+        for (int i = tid; i < GATHER_MAX_CHILD * NB; i += 256) inv0[i / NB][i % NB] = -1;
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {               // rel is increasing: only its first entries can be < 32
+            const int32_t* rl = rel + cR[ch];
+            const int lim = min(cB[ch], NB);
+            if (tid < lim) {
+                const int g = rl[tid];
+                if (g < NB) inv0[ch][g] = tid;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int rr = i % NB, c = i / NB;
+            double v = 0.0;
+            if (rr >= c && rr < nb) {
+                for (int ch = 0; ch < nch; ++ch) {        // child order: the summation order of the extend-add
+                    const int jc = inv0[ch][c], ir = inv0[ch][rr];
+                    if (jc >= 0 && ir >= 0) v += arena[cU[ch] + (int64_t)jc * cM[ch] + ir];
+                }
+            }
+            Dn[rr][c] = v;
+        }
+        __syncthreads();
+        {
+            const int32_t* cp = a_colptr + F.acol_off;
+            const int end = cp[nb];
+            const int32_t* ad = a_dst + F.a_off;
+            for (int t = tid; t < end; t += 256) {
+                const int d = ad[t], lu = d % m, lv = d / m;
+                if (lu < nb) Dn[lu][lv] += Hval[a_src[F.a_off + t]];
+            }
+        }
+        __syncthreads();
+        block_ldlt32_b4(Dn, dq, nb, tid, colbuf, Sp4, Lp4, status);
+        block_inverse32(Dn, Wv, Tm, tid);
+        double* slot = dscr + (int64_t)blockIdx.y * 2 * (NB * NB);
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int rr = i % NB, c = i / NB;
+            if (rr >= c && rr < nb) slot[rr + NB * c] = (rr == c) ? dq[rr] : Wv[rr][c];
+        }
+        return;
+    }
+    const int c0 = blockIdx.x * CT;
+    if (c0 >= m) return;
+    const int c1 = min(c0 + CT, m);
+    double* W = arena + F.F_off;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;     // one wave per destination column, lanes on the rows
+    const int nch = F.nchild;
+    if (tid < nch) {
+        const FrontDev C = fr[children[F.child_off + tid]];
+        cU[tid] = C.F_off + (int64_t)C.k * C.m + C.k;
+        cR[tid] = C.rel_off;
+        cM[tid] = C.m;
+        cB[tid] = C.m - C.k;
+    }
+    for (int i = tid; i < nch * mstride; i += 256) inv[i] = -1;
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int32_t* rl = rel + cR[ch];
+        const int b = cB[ch];
+        for (int j = tid; j < b; j += 256) inv[ch * mstride + rl[j]] = j;
+    }
+    __syncthreads();
+    for (int c = c0 + wave; c < c1; c += 4) {
+        double* Wc = W + (int64_t)c * m;
+        int64_t colbase[GATHER_MAX_CHILD];         // child column offset, -1 when the child does not reach column c
+#pragma unroll
+        for (int ch = 0; ch < GATHER_MAX_CHILD; ++ch) {
+            const int jc = ch < nch ? inv[ch * mstride + c] : -1;
+            colbase[ch] = jc >= 0 ? cU[ch] + (int64_t)jc * cM[ch] : -1;
+        }
+        for (int r = c + lane; r < m; r += 128) {  // two rows per lane in flight
+            const int r1 = r + 64;
+            double u0[GATHER_MAX_CHILD], u1[GATHER_MAX_CHILD];
+#pragma unroll
+            for (int ch = 0; ch < GATHER_MAX_CHILD; ++ch) {
+                u0[ch] = 0.0;
+                u1[ch] = 0.0;
+                if (colbase[ch] >= 0) {
+                    const int i0 = inv[ch * mstride + r];
+                    const int i1 = r1 < m ? inv[ch * mstride + r1] : -1;
+                    if (i0 >= 0) u0[ch] = arena[colbase[ch] + i0];
+                    if (i1 >= 0) u1[ch] = arena[colbase[ch] + i1];
+                }
+            }
+            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < GATHER_MAX_CHILD; ++ch) {      // child order: the summation order of the extend-add
+                v0 += u0[ch];
+                v1 += u1[ch];
+            }
+            Wc[r] = v0;
+            if (r1 < m) Wc[r1] = v1;
+        }
+    }
+    __syncthreads();
+    {   // A entries are grouped by pivot column: the per-column offsets give the range of [c0, c1)
+        const int32_t* cp = a_colptr + F.acol_off;
+        const int beg = cp[min(c0, F.k)], end = cp[min(c1, F.k)];
+        const int32_t* ad = a_dst + F.a_off;
+        for (int t = beg + tid; t < end; t += 256) W[ad[t]] += Hval[a_src[F.a_off + t]];
+    }
+}
+
 // ---- triangular solves on the inverse-based layout: one workgroup per front --------------------
 // forward, block j of a front:  u_j = M_j t_j,  t[r] -= A[r, j] u_j  (r below);  the stored intermediate is u
 // (M_j = A_jj^{-1} of the updated diagonal block = W_j' D_j^{-1} W_j, written home by mf_big_step)
@@ -2288,14 +2352,18 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
 static StageTimers g_dummy_timers;
 static StageTimers* timers_or_dummy(StageTimers* t, bool on) { return (t && on) ? t : &g_dummy_timers; }
 
-void MfSolver::launch_big_assemble(const MfLaunch& L, dim3 ga, const double* d_values, const int32_t* a_src_p, hipStream_t st) {
+bool MfSolver::launch_big_assemble(const MfLaunch& L, dim3 ga, const double* d_values, const int32_t* a_src_p, hipStream_t st,
+                                   bool with_diag) {
     const size_t lds = (size_t)L.max_child * (size_t)L.max_m * sizeof(int32_t);
-    if (L.max_child >= 1 && L.max_child <= GATHER_MAX_CHILD && lds <= 60 * 1024)
+    if (L.max_child >= 1 && L.max_child <= GATHER_MAX_CHILD && lds <= 40 * 1024) {
+        if (with_diag) ga.x += 1;          // the diagonal-block workgroup
         hipLaunchKernelGGL(mf_big_gather, ga, dim3(256), lds, st, d_fronts.p, L.first, d_children.p, d_rel.p, a_src_p,
-                           d_a_dst.p, d_a_colptr.p, d_values, d_arena.p, L.max_m);
-    else
+                           d_a_dst.p, d_a_colptr.p, d_values, d_arena.p, L.max_m, d_dscr.p, d_status.p, with_diag ? 1 : 0);
+        return with_diag;
+    } else
         hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p, a_src_p,
                            d_a_dst.p, d_a_colptr.p, d_values, d_arena.p);
+    return false;
 }
 
 void MfSolver::set_direct_map(const int32_t* value_map, int64_t nnz, int64_t tail_base, hipStream_t st) {
@@ -2357,10 +2425,11 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
 #undef MGB_LAUNCH_SMALL
             } else if (L.inv && !robust) {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
-                launch_big_assemble(L, ga, d_values, a_src_p, st);
-                // many fronts: factor block 0 once per front up front instead of inside every tile of step 0
-                const bool pre_diag = L.count >= 24;
-                if (pre_diag)
+                // block 0 of every front is factored by an extra workgroup of the gather launch when that kernel applies;
+                // otherwise once per front up front (many fronts) or inside every tile of step 0 (few fronts)
+                const bool diag_done = launch_big_assemble(L, ga, d_values, a_src_p, st, true);
+                const bool pre_diag = diag_done || L.count >= 24;
+                if (pre_diag && !diag_done)
                     hipLaunchKernelGGL(mf_big_diag0, dim3(L.count), dim3(256), 0, st, d_fronts.p, L.first, d_arena.p, d_dscr.p,
                                        d_status.p);
                 for (int j0 = 0; j0 < L.max_k; j0 += NB) {
@@ -2372,7 +2441,7 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 }
             } else {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
-                launch_big_assemble(L, ga, d_values, a_src_p, st);
+                launch_big_assemble(L, ga, d_values, a_src_p, st, false);
                 for (int j0 = 0; j0 < L.max_k; j0 += NB) {
                     const int rem = L.max_m - j0;                // rows from the panel start, at most
                     const dim3 gp(std::max(1, (rem - 1 + TR - 1) / TR), L.count);

@@ -62,7 +62,8 @@ class MfSolver {
     bool factored_inv = false;
 
    private:
-    void launch_big_assemble(const MfLaunch& L, dim3 grid, const double* d_values, const int32_t* a_src_p, hipStream_t st);
+    bool launch_big_assemble(const MfLaunch& L, dim3 grid, const double* d_values, const int32_t* a_src_p, hipStream_t st,
+                             bool with_diag);     // returns true when block 0 of every front was factored by the launch
     void forward_pass(const double* d_b_np1, hipStream_t st, StageTimers* timers);
     void backward_pass(double* d_x_np1, hipStream_t st, StageTimers* timers);
     DevBuf<double> d_bx, d_xx, d_one;     // bordered right-hand side / solution of solve(), the constant 1
