@@ -2197,6 +2197,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     d_arena.alloc((size_t)std::max<int64_t>(plan.arena_doubles, 1));
     d_uvec.alloc((size_t)std::max<int64_t>(plan.uvec_doubles, 1));
     d_y.alloc((size_t)plan.n + 1);            // + the border unknown
+    y_border_one = false;
     d_bx.alloc((size_t)plan.n + 1);
     d_xx.alloc((size_t)plan.n + 1);
     {
@@ -2482,13 +2483,17 @@ void MfSolver::solve_border(double* d_x_np1, hipStream_t st, StageTimers* timers
     // front.  L' x = e_n backwards from x_n = 1 gives x[0:n] = H^{-1} g.
     const size_t n = (size_t)plan.n;
     MGB_HIP_CHECK(hipMemsetAsync(d_y.p, 0, n * sizeof(double), st));
-    MGB_HIP_CHECK(hipMemcpyAsync(d_y.p + n, d_one.p, sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (!y_border_one) {             // y[n] = 1 survives the backward sweeps: set once (a generic forward sweep overwrites it)
+        MGB_HIP_CHECK(hipMemcpyAsync(d_y.p + n, d_one.p, sizeof(double), hipMemcpyDeviceToDevice, st));
+        y_border_one = true;
+    }
     backward_pass(d_x_np1, st, timers);
     MGB_HIP_CHECK(hipGetLastError());
     if (timers) timers->end();
 }
 
 void MfSolver::forward_pass(const double* d_b, hipStream_t st, StageTimers* timers) {
+    y_border_one = false;
     static const bool lvl_timing = [] { const char* e = getenv("MGBHIP_LEVEL_TIMING"); return e && e[0] == '1'; }();
     int lvno = -1;
     for (auto& lev : level_solves) {

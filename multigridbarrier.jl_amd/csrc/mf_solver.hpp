@@ -76,6 +76,7 @@ class MfSolver {
     std::vector<std::vector<MfLaunch>> level_solves;     // triangular solves: all LDS-class fronts of a level in one launch
     int32_t lds_cap = 88;           // largest m factored out of LDS
     bool uses_inv = false;
+    bool y_border_one = false;      // d_y[n] holds the 1 the border sweep starts from
 };
 
 }  // namespace mgbhip
