@@ -1,6 +1,6 @@
 """Debug helper (CPU, imports the oracle: development only): the oracle on the reference-default hierarchy at L=8, p=1.5."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import mgb_amd as m
 from oracle import mgb_oracle as O

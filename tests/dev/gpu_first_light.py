@@ -1,6 +1,6 @@
 """First-light GPU check: per-primitive parity against the oracle, then golden solves."""
 import json, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 import mgb_amd as m
 from mgb_amd.device import DeviceMGBProblem

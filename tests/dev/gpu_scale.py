@@ -1,6 +1,6 @@
 """Scale check on the GPU: end-to-end solves with stage timers; oracle comparison at small L."""
 import json, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import mgb_amd as m
 from mgb_amd.device import DeviceMGBProblem
