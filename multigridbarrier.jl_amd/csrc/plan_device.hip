@@ -261,6 +261,13 @@ void build_plan_device(const PlanDeviceIn& in, Level& L, hipStream_t st) {
         vmap.download(L.h_vmap.data(), (size_t)nnz, st);
         MGB_HIP_CHECK(hipStreamSynchronize(st));
         L.nshared = (int64_t)lr + lf;
+        if (L.nshared < nnz) {               // keep only the used part of the list
+            DevBuf<int32_t> sq;
+            sq.alloc((size_t)std::max<int64_t>(L.nshared, 1));
+            if (L.nshared) MGB_HIP_CHECK(hipMemcpyAsync(sq.p, L.sh_q.p, (size_t)L.nshared * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            MGB_HIP_CHECK(hipStreamSynchronize(st));
+            L.sh_q = std::move(sq);
+        }
         L.direct = true;
     }
 }
