@@ -137,7 +137,9 @@ def _rs_cf_splitting(S: sp.csr_matrix, diag_quirk: bool = False) -> np.ndarray:
     return np.array(split) == C_NODE
 
 
-def _direct_interpolation(A: sp.csr_matrix, S: sp.csr_matrix, is_c: np.ndarray) -> sp.csr_matrix:
+def _direct_interpolation_loop(A: sp.csr_matrix, S: sp.csr_matrix, is_c: np.ndarray) -> sp.csr_matrix:
+    """Row-by-row statement of the direct interpolation (kept as the readable reference and the test twin of the
+    vectorised `_direct_interpolation` below: tests/test_setup.py compares the two bit for bit)."""
     n = A.shape[0]
     A = sp.csr_matrix(A)
     cidx = np.cumsum(is_c) - 1
@@ -179,6 +181,39 @@ def _direct_interpolation(A: sp.csr_matrix, S: sp.csr_matrix, is_c: np.ndarray) 
             j, v = Aj[jj], Ax[jj]
             if j != i and is_c[j] and j in sset:
                 rows.append(i); cols.append(int(cidx[j])); vals.append((neg_c if v < 0 else pos_c) * v)
+    return sp.csr_matrix((vals, (rows, cols)), shape=(n, nc))
+
+
+def _direct_interpolation(A: sp.csr_matrix, S: sp.csr_matrix, is_c: np.ndarray) -> sp.csr_matrix:
+    """Direct interpolation, vectorised over the entries of A.  Every per-row sum is a `np.bincount` over the
+    entries in storage order, i.e. the same sequence of additions as the row loop above: identical bits."""
+    n = A.shape[0]
+    A = sp.csr_matrix(A)
+    is_c = np.asarray(is_c, dtype=bool)
+    cidx = np.cumsum(is_c) - 1
+    nc = int(is_c.sum())
+    Ap, Aj, Ax = A.indptr, A.indices.astype(np.int64), A.data
+    row = np.repeat(np.arange(n, dtype=np.int64), np.diff(Ap))
+    Sb = sp.csr_matrix(S).astype(bool).tocoo()
+    in_S = np.isin(row * n + Aj, Sb.row.astype(np.int64) * n + Sb.col.astype(np.int64))
+    offd = Aj != row
+    neg = Ax < 0
+    strong_c = offd & is_c[Aj] & in_S
+    bc = lambda mask: np.bincount(row[mask], weights=Ax[mask], minlength=n)
+    diag = bc(~offd)
+    sum_all_neg, sum_all_pos = bc(offd & neg), bc(offd & ~neg)
+    sum_s_neg, sum_s_pos = bc(strong_c & neg), bc(strong_c & ~neg)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        alpha = np.where(sum_s_neg != 0, sum_all_neg / sum_s_neg, 0.0)
+        beta = np.where(sum_s_pos == 0, 0.0, sum_all_pos / sum_s_pos)
+        diag = np.where(sum_s_pos == 0, diag + sum_all_pos, diag)
+        neg_c, pos_c = -alpha / diag, -beta / diag
+    keep = strong_c & ~is_c[row] & (diag[row] != 0)
+    f_vals = np.where(neg[keep], neg_c[row[keep]], pos_c[row[keep]]) * Ax[keep]
+    c_rows = np.nonzero(is_c)[0]
+    rows = np.concatenate([c_rows, row[keep]])
+    cols = np.concatenate([cidx[c_rows], cidx[Aj[keep]]])
+    vals = np.concatenate([np.ones(c_rows.size), f_vals])
     return sp.csr_matrix((vals, (rows, cols)), shape=(n, nc))
 
 

@@ -187,3 +187,28 @@ def test_rs_level_sizes_of_the_baseline_meshes():
         sizes[L] = ([R.shape[1] for R in mg.R["full"]], [R.shape[1] for R in mg.R["dirichlet"]])
     assert sizes[5] == ([1, 3, 9, 36, 144, 289, 3584], [1, 7, 28, 112, 225, 1473, 1473])
     assert sizes[7] == ([1, 4, 11, 37, 138, 543, 2113, 4225, 57344], [1, 8, 33, 126, 509, 1985, 3969, 24321, 24321])
+
+
+def test_vectorised_direct_interpolation_is_bitwise_the_row_loop():
+    """f4: the setup layer's direct interpolation runs vectorised over the matrix entries; its per-row sums are
+    `np.bincount`s in storage order, the same additions as the readable row loop kept beside it."""
+    from mgb_amd import amg_prolongators as ap
+    n = 48
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+    A = sp.csr_matrix(sp.kron(sp.identity(n), T) + sp.kron(T, sp.identity(n)))
+    rng = np.random.default_rng(3)
+    A = sp.csr_matrix(A + sp.diags(rng.uniform(0.0, 0.5, A.shape[0])))          # break the symmetry of the sums
+    A.data[rng.integers(0, A.nnz, 40)] *= -0.3                                   # a few positive off-diagonals
+    for level in range(4):
+        S = ap._classical_strength(A, 0.25)
+        is_c = ap._rs_cf_splitting(S, False)
+        P1 = ap._direct_interpolation_loop(A, S, is_c)
+        P2 = ap._direct_interpolation(A, S, is_c)
+        for P in (P1, P2):
+            P.sum_duplicates()
+            P.sort_indices()
+        assert np.array_equal(P1.indptr, P2.indptr) and np.array_equal(P1.indices, P2.indices)
+        assert np.array_equal(P1.data, P2.data)
+        if is_c.sum() in (0, A.shape[0]):
+            break
+        A = sp.csr_matrix(P2.T @ A @ P2)
