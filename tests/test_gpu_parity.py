@@ -644,3 +644,35 @@ def test_config4_default_start_phase1_full_size():
         assert sol.SOL_main["ts"][-1] >= 1.0 / np.sqrt(np.finfo(float).eps)
     finally:
         sol.device.close()
+
+
+def test_generic_solves_and_newton_solves_share_one_factorization_plan():
+    """Every system is analysed bordered; the Newton loop factors [H -g; -g' -1] (the forward substitution rides
+    along, one backward sweep follows, and on the fine level H is not even materialised), the API factors the
+    block-diagonal border and runs both sweeps.  Alternating the two on one resident problem must keep both exact:
+    solve -> API f2 + solve against SciPy -> solve again bitwise."""
+    import scipy.sparse.linalg as spla
+    from mgb_amd.solve import mgb_driver
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 4)), p=1.5)
+    sol = m.mgb_solve(prob, keep_device=True)
+    try:
+        P = sol.device.main
+        J = len(P.level_sizes) - 1
+        z0 = stacked(prob.g)
+        c = 0.1 * prob.f
+        rng = np.random.default_rng(11)
+        for level in (J, J - 1, 0):
+            s = 1e-4 * rng.standard_normal(P.level_sizes[level])
+            H = sp.csc_matrix(P.f2(level, s, c, z0))
+            g = P.f1(level, s, c, z0)
+            x = P.solve(level, g)
+            x_ref = spla.spsolve(H, g)
+            assert np.linalg.norm(x - x_ref) <= 1e-9 * np.linalg.norm(x_ref)
+            b2 = rng.standard_normal(g.size)                     # a second right-hand side on the same factors
+            x2 = P.solve(level, b2)
+            assert np.linalg.norm(H @ x2 - b2) <= 1e-9 * np.linalg.norm(b2)
+        again = mgb_driver(sol.device)
+        assert np.array_equal(again["z"], sol.z)
+        assert np.array_equal(again["SOL_main"]["its"], sol.SOL_main["its"])
+    finally:
+        sol.device.close()
