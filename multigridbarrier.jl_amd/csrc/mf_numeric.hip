@@ -2283,7 +2283,9 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             for (auto& L : level_launches[l]) {
                 int stride = 0;
                 if (L.tiny) stride = 16;
-                else if (L.cls && L.cls <= 48 && !no_wave) {
+                else if (L.cls && L.cls <= 48 && !no_wave && plan.n >= 1024) {      // large systems only, like the inverse path:
+                    // on fem2d_P2 L=5 p=3.5 the 37-unknown level creeps along the barrier wall for thousands of iterations and the
+                    // register-resident elimination returned lambda^2 with 1e-2 relative noise there (1e-5 with the blocked kernel)
                     bool ok = true;
                     for (int32_t q = L.first; q < L.first + L.count && ok; ++q) {
                         const Front& f = plan.fronts[q];
