@@ -198,8 +198,7 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
             P->factor(C.level, P->d_g.p);                   // the gradient rides along: no forward sweep afterwards
             P->trisolve_carried(C.level, P->d_nv.p);
             // pivot flag, direction statistics and lambda^2 = <g, n> in one round trip
-            launch_vec_stats(P->d_nv.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st);
-            launch_dot(P->d_g.p, P->d_nv.p, C.m, P->d_scratch.p, P->d_scal.p + 4, st);
+            launch_dir_stats(P->d_nv.p, P->d_g.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st);
             MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
             L.solver.status_async(P->pin.i + 1, st);
             MGB_HIP_CHECK(hipStreamSynchronize(st));

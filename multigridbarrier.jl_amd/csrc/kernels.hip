@@ -628,6 +628,36 @@ __global__ __launch_bounds__(256) void block_reduce_kernel(const double* __restr
     }
 }
 
+// Newton direction statistics in one pass: sum v*v, count of non-finite v, and g.v (the same per-block partial sums
+// and trees as block_reduce_kernel<1> and <0>: identical values, two launches fewer per Newton iteration)
+__global__ __launch_bounds__(256) void dir_stats_kernel(const double* __restrict__ v, const double* __restrict__ g, int64_t n,
+                                                        double* __restrict__ partials) {
+    __shared__ double red[3][256];
+    const int tid = threadIdx.x;
+    double s = 0.0, bad = 0.0, d = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+        const double x = v[i];
+        s += x * x;
+        bad += isfinite(x) ? 0.0 : 1.0;
+        d += g[i] * x;
+    }
+    red[0][tid] = s; red[1][tid] = bad; red[2][tid] = d;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            red[0][tid] += red[0][tid + off];
+            red[1][tid] += red[1][tid + off];
+            red[2][tid] += red[2][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        partials[blockIdx.x] = red[0][0];
+        partials[gridDim.x + blockIdx.x] = red[1][0];
+        partials[2 * gridDim.x + blockIdx.x] = red[2][0];
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce2_kernel(const double* __restrict__ partials, int nb,
                                                       double* __restrict__ out, int nout) {
     __shared__ double red[256];
@@ -747,6 +777,13 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const double* __restric
                                                          double* __restrict__ dst, int64_t len) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < len) dst[i] = alpha * src[i];
+}
+
+// border column of the bordered Newton system: tail[0 .. m) = -g, tail[m] = -1 (one launch)
+__global__ __launch_bounds__(256) void border_tail_kernel(const double* __restrict__ g, double* __restrict__ tail, int64_t m) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) tail[i] = -1.0 * g[i];
+    else if (i == m) tail[i] = -1.0;
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(double alpha, const double* __restrict__ x,
@@ -1283,12 +1320,19 @@ static int reduce_blocks(int64_t n) {
     return (int)b;
 }
 
-int64_t reduce_scratch_doubles(int64_t n) { return 2 * (int64_t)reduce_blocks(n); }
+int64_t reduce_scratch_doubles(int64_t n) { return 3 * (int64_t)reduce_blocks(n); }
 
 void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st) {
     const int nb = reduce_blocks(n);
     hipLaunchKernelGGL(block_reduce_kernel<1>, dim3(nb), dim3(256), 0, st, v, (const double*)nullptr, n, scratch);
     hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats, 2);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_dir_stats(const double* v, const double* g, int64_t n, double* scratch, double* stats3, hipStream_t st) {
+    const int nb = reduce_blocks(n);
+    hipLaunchKernelGGL(dir_stats_kernel, dim3(nb), dim3(256), 0, st, v, g, n, scratch);
+    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats3, 3);
     MGB_HIP_CHECK(hipGetLastError());
 }
 
@@ -1344,6 +1388,11 @@ void launch_step(const double* x, const double* n, double s, double* xn, int64_t
 void launch_scale_copy(const double* src, double alpha, double* dst, int64_t len, hipStream_t st) {
     if (len == 0) return;
     hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, src, alpha, dst, len);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_border_tail(const double* g, double* tail, int64_t m, hipStream_t st) {
+    hipLaunchKernelGGL(border_tail_kernel, dim3((unsigned)((m + 1 + 255) / 256)), dim3(256), 0, st, g, tail, m);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

@@ -58,6 +58,8 @@ void launch_elem(const ElemParams& P, int mode, hipStream_t st);
 void launch_reduce_partials(const double* partials, int64_t count, double* out, hipStream_t st);
 // stats[0] = sum v^2, stats[1] = number of non-finite entries (as double)
 void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st);
+// stats3 = [sum v*v, count of non-finite v, g.v] in one pass (values identical to launch_vec_stats + launch_dot)
+void launch_dir_stats(const double* v, const double* g, int64_t n, double* scratch, double* stats3, hipStream_t st);
 void launch_dot(const double* a, const double* b, int64_t n, double* scratch, double* out, hipStream_t st);
 int64_t reduce_scratch_doubles(int64_t n);
 
@@ -74,6 +76,7 @@ void launch_prolong(int64_t rows, const int32_t* ptr, const int32_t* col, const 
 void launch_step(const double* x, const double* n, double s, double* xn, int64_t len, int32_t* moved,
                  hipStream_t st);
 void launch_scale_copy(const double* src, double alpha, double* dst, int64_t len, hipStream_t st);
+void launch_border_tail(const double* g, double* tail, int64_t m, hipStream_t st);   // tail = [-g; -1]
 void launch_axpy(double alpha, const double* x, double* y, int64_t len, hipStream_t st);
 void launch_fill(double value, double* y, int64_t len, hipStream_t st);       // y[:] = value
 

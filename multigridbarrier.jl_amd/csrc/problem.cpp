@@ -815,8 +815,7 @@ void mgbhip_problem::factor(int level, const double* rhs) {
             std::vector<int32_t>().swap(L.h_vmap);        // 4 B per nonzero: not needed again
         }
         double* tail = d_hel.p + hel_cap + L.nshared;
-        launch_scale_copy(rhs, -1.0, tail, L.m, st);
-        launch_fill(-1.0, tail + L.m, 1, st);
+        launch_border_tail(rhs, tail, L.m, st);
         L.solver.factor(d_hel.p, st, &ctx->timers, true);
         L.border_state2 = 2;
         L.factored = true;
@@ -825,8 +824,7 @@ void mgbhip_problem::factor(int level, const double* rhs) {
     }
     L.border_state2 = 0;
     if (rhs) {          // border column -g, corner -1: the factorization carries the forward substitution of H x = g
-        launch_scale_copy(rhs, -1.0, L.Hval.p + L.nnz, L.m, st);
-        launch_fill(-1.0, L.Hval.p + L.nnz + L.m, 1, st);
+        launch_border_tail(rhs, L.Hval.p + L.nnz, L.m, st);
         L.border_state = 2;
     } else if (L.border_state != 1) {       // border column 0, corner 1: block diagonal, ordinary solves
         MGB_HIP_CHECK(hipMemsetAsync(L.Hval.p + L.nnz, 0, sizeof(double) * (size_t)L.m, st));
