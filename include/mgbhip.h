@@ -183,6 +183,14 @@ int mgbhip_hessian_pattern(mgbhip_problem* prob, int32_t level, int64_t* nnz,
 /* n = solve(symmetric(H), g) with the H of the last mgbhip_f2 at this level
  * (src/newton.jl:253, src/utils.jl:142-145): sparse Cholesky on the device.              */
 int mgbhip_solve(mgbhip_problem* prob, int32_t level, const double* g, double* x);
+/* The reference's `solve(A, b)` hook (src/utils.jl:142-145; cuDSS twin cudss_solver.jl:396-408) takes any
+ * matrix with the level's sparsity pattern: replace the values of H (CSR order of mgbhip_hessian_pattern);
+ * the next mgbhip_solve / mgbhip_solve_newton factors them.                                                */
+int mgbhip_set_hessian(mgbhip_problem* prob, int32_t level, const double* values /* nnz */);
+/* The solve exactly as the resident Newton loop performs it (src/newton.jl:253-255): the bordered matrix
+ * [H -g; -g' -1] is factored, so the forward substitution rides along the factorization, and one backward
+ * sweep returns x = H^{-1} g; lambda2 (optional) = <g, x>.                                                  */
+int mgbhip_solve_newton(mgbhip_problem* prob, int32_t level, const double* g, double* x, double* lambda2);
 /* Per-node barrier value map_rows_gpu(F0, args..., Dz(z)) (src/mgb.jl:410-420) and the
  * slack initialiser (src/mgb.jl:437-440); y is n x nD column-major.                      */
 int mgbhip_node_barrier(mgbhip_problem* prob, const double* z, double* F /* n */, double* Dz /* n*nD or NULL */);

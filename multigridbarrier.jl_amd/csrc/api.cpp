@@ -218,6 +218,44 @@ int mgbhip_solve(mgbhip_problem* P, int32_t level, const double* g, double* x) {
     MGB_API_END
 }
 
+int mgbhip_set_hessian(mgbhip_problem* P, int32_t level, const double* values) {
+    MGB_API_BEGIN_ON(P)
+    check_level(P, level);
+    MGB_REQUIRE(values, "null argument");
+    P->ensure_plan(level);
+    mgbhip::Level& L = P->levels[level];
+    MGB_REQUIRE(L.Hval.n >= (size_t)L.nnz, "this level keeps no CSR value array");
+    L.Hval.upload(values, (size_t)L.nnz, P->stream());
+    MGB_HIP_CHECK(hipStreamSynchronize(P->stream()));
+    L.have_H = true;
+    L.H_in_slab = false;
+    L.factored = false;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_solve_newton(mgbhip_problem* P, int32_t level, const double* g, double* x, double* lambda2) {
+    MGB_API_BEGIN_ON(P)
+    check_level(P, level);
+    MGB_REQUIRE(g && x, "null argument");
+    hipStream_t st = P->stream();
+    const size_t m = (size_t)P->levels[level].m;
+    P->d_g.upload(g, m, st);
+    P->factor(level, P->d_g.p);                    // [H -g; -g' -1]: the forward substitution rides along
+    P->trisolve_carried(level, P->d_nv.p);         // one backward sweep from x_n = 1
+    const int status = P->levels[level].solver.status(st);
+    P->d_nv.download(x, m, st);
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (lambda2) {
+        double acc = 0.0;
+        for (size_t i = 0; i < m; ++i) acc += g[i] * x[i];
+        *lambda2 = acc;
+    }
+    if (status != MGBHIP_OK) g_last_error = "Cholesky met a non-positive pivot";
+    return status;
+    MGB_API_END
+}
+
 
 // ---- device-resident vectors --------------------------------------------------------------------
 static double* vec_scratch(mgbhip_ctx* c, int64_t len) {

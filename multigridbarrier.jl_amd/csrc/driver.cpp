@@ -189,6 +189,10 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
     int k = 0;
     bool converged = false;
     Level& L = P->levels[C.level];
+    struct RobustReset {          // the next Newton solve starts on the fast kernels again, whichever way this one ends
+        MfSolver& s;
+        ~RobustReset() { s.robust = false; }
+    } robust_reset{L.solver};
     while (k < maxit && !converged) {
         ++k;
         C.F2(P->d_x.p);
@@ -206,7 +210,10 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
             // The fast large-front kernels apply inverted 32 x 32 diagonal blocks; near the edge of singularity
             // that loses digits a substitution keeps.  A failed pivot, a non-finite direction or lambda^2 <= 0
             // is re-done once with the substitution kernels before the reference's own tests see it.
-            const bool suspicious = fstatus != MGBHIP_OK || P->pin.d[3] != 0.0 || !std::isfinite(P->pin.d[2]) || !(P->pin.d[4] > 0);
+            // (lambda^2 <= 0 within EPS * max(|y|, 1) is the reference's legitimate round-off-floor exit, src/newton.jl:257-271)
+            const bool at_floor = std::fabs(P->pin.d[4]) <= EPS * std::fmax(std::fabs(y), 1.0);
+            const bool suspicious = fstatus != MGBHIP_OK || P->pin.d[3] != 0.0 || !std::isfinite(P->pin.d[2]) ||
+                                    (!(P->pin.d[4] > 0) && !at_floor);
             if (!suspicious || attempt == 1 || !L.solver.has_inverse_path() || L.solver.robust) break;
             DBG("newton[lev %d] k=%d: direction rejected (status %d, lambda^2=%.3e): refactoring with the substitution kernels\n",
                 C.level, k, fstatus, P->pin.d[4]);
@@ -246,7 +253,6 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         ymin = std::fmin(ymin, y);
         incmin = std::fmin(inc, incmin);
     }
-    L.solver.robust = false;          // the next Newton solve starts on the fast kernels again
     DBG("newton[lev %d] done k=%d converged=%d y=%.17g\n", C.level, k, (int)converged, y);
     R.k = k;
     R.converged = converged;

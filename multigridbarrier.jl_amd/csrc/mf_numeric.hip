@@ -2235,6 +2235,9 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
         }
     }
     static const int32_t classes[] = {16, 32, 48, 64, 88, 128};
+    // size gates of the two fastest kernel families (A/B switches for tests/test_gpu_solver.py)
+    static const int64_t inv_min_n = [] { const char* e = getenv("MGBHIP_INV_MIN_N"); return e ? atoll(e) : 1024ll; }();
+    static const int64_t wave_min_n = [] { const char* e = getenv("MGBHIP_WAVE_MIN_N"); return e ? atoll(e) : 1024ll; }();
     uses_inv = false;
     level_launches.clear();
     const int32_t nlev = (int32_t)plan.level_ptr.size() - 1;
@@ -2262,7 +2265,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             L.tiny = (l == 0 && cls == 16);     // leaves with m <= 16: 16 lanes per front
             // inverse-based path: large systems only (small coarse systems cost nothing either way and are the ones
             // the barrier method drives to the edge of singularity, where substitution is the safer arithmetic)
-            L.inv = (cls == 0 && L.max_m <= BIG_INV_MAX_M && inv_ok && plan.n >= 1024);
+            L.inv = (cls == 0 && L.max_m <= BIG_INV_MAX_M && inv_ok && plan.n >= inv_min_n);
             uses_inv = uses_inv || L.inv;
             for (int32_t q = i; q < j; ++q) {
                 L.max_k = std::max(L.max_k, plan.fronts[q].k);
@@ -2283,7 +2286,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             for (auto& L : level_launches[l]) {
                 int stride = 0;
                 if (L.tiny) stride = 16;
-                else if (L.cls && L.cls <= 48 && !no_wave && plan.n >= 1024) {      // large systems only, like the inverse path:
+                else if (L.cls && L.cls <= 48 && !no_wave && plan.n >= wave_min_n) {      // large systems only, like the inverse path:
                     // on fem2d_P2 L=5 p=3.5 the 37-unknown level creeps along the barrier wall for thousands of iterations and the
                     // register-resident elimination returned lambda^2 with 1e-2 relative noise there (1e-5 with the blocked kernel)
                     bool ok = true;

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import List, Optional
 
 import numpy as np
@@ -105,6 +106,7 @@ EXPORTS = [
     "mgbhip_create", "mgbhip_destroy", "mgbhip_last_error", "mgbhip_version", "mgbhip_problem_create",
     "mgbhip_problem_destroy", "mgbhip_problem_set_box", "mgbhip_problem_set_barrier_weights",
     "mgbhip_level_size", "mgbhip_f0", "mgbhip_f1", "mgbhip_f2", "mgbhip_hessian_pattern", "mgbhip_solve",
+    "mgbhip_set_hessian", "mgbhip_solve_newton",
     "mgbhip_node_barrier", "mgbhip_node_slack", "mgbhip_mgb_core", "mgbhip_matched_t",
     "mgbhip_default_options", "mgbhip_stage_ms", "mgbhip_reset_stage_timers", "mgbhip_solver_stats",
     "mgbhip_vec_alloc", "mgbhip_vec_free", "mgbhip_vec_len", "mgbhip_vec_upload", "mgbhip_vec_download",
@@ -146,6 +148,8 @@ def load_library():
         getattr(lib, name).argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp]
     lib.mgbhip_hessian_pattern.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(_ip), C.POINTER(_ip)]
     lib.mgbhip_solve.argtypes = [C.c_void_p, C.c_int32, _dp, _dp]
+    lib.mgbhip_set_hessian.argtypes = [C.c_void_p, C.c_int32, _dp]
+    lib.mgbhip_solve_newton.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp]
     lib.mgbhip_node_barrier.argtypes = [C.c_void_p, _dp, _dp, _dp]
     lib.mgbhip_node_slack.argtypes = [C.c_void_p, _dp, _dp]
     lib.mgbhip_mgb_core.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(Options), C.POINTER(_CoreResult)]
@@ -205,9 +209,12 @@ class HipContext:
         h = C.c_void_p()
         _check(self.lib, self.lib.mgbhip_create(C.byref(h), int(device_id), C.c_void_p(stream) if stream else None))
         self.handle = h
+        self._vectors = weakref.WeakSet()      # live DeviceVectors: freed before the context they point into
 
     def close(self):
         if self.handle:
+            for v in list(self._vectors):
+                v.close()
             self.lib.mgbhip_destroy(self.handle)
             self.handle = None
 
@@ -231,6 +238,7 @@ class DeviceVector:
         h = C.c_void_p()
         _check(self.lib, self.lib.mgbhip_vec_alloc(ctx.handle, int(length), C.byref(h)))
         self.handle, self.n = h, int(length)
+        ctx._vectors.add(self)
         if data is not None and length:
             _check(self.lib, self.lib.mgbhip_vec_upload(h, _ptr(data), length))
 
@@ -283,7 +291,8 @@ class DeviceVector:
 
     def close(self):
         if self.handle:
-            self.lib.mgbhip_vec_free(self.handle)
+            if self.ctx.handle:                # mgbhip_vec_free dereferences the context: never after mgbhip_destroy
+                self.lib.mgbhip_vec_free(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -471,6 +480,21 @@ class DeviceProblem:
         x = np.empty_like(g)
         _check(self.lib, self.lib.mgbhip_solve(self.handle, level, _ptr(g), _ptr(x)))
         return x
+
+    def set_hessian(self, level: int, values) -> None:
+        """Replace the values of the level's H (CSR order of `hessian_pattern`); the next solve factors them."""
+        v = _f64(np.asarray(values, dtype=np.float64).reshape(-1))
+        _check(self.lib, self.lib.mgbhip_set_hessian(self.handle, level, _ptr(v)))
+
+    def solve_newton(self, level: int, g, check: bool = True):
+        """x = H^{-1} g through the bordered factorization of the resident Newton loop; returns (x, lambda^2, status)."""
+        g = _f64(g)
+        x = np.empty_like(g)
+        lam = C.c_double()
+        status = self.lib.mgbhip_solve_newton(self.handle, level, _ptr(g), _ptr(x), C.cast(C.byref(lam), _dp))
+        if check:
+            _check(self.lib, status)
+        return x, lam.value, status
 
     def node_barrier(self, z, want_Dz: bool = False):
         z = _f64(z)

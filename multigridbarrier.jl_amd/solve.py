@@ -103,10 +103,24 @@ def _options(P, tol, t, kappa, maxit, max_newton, line_search, stopping_criterio
                 o.ls_beta = float(args[0])
         else:
             raise ValueError("line_search must be ('backtracking', beta, c1) or ('illinois', beta)")
+    if keep is None:
+        keep = []
+    o._keep = keep                     # the thunks live as long as the options object that points at them
     if callable(stopping_criterion):
         fn = stopping_criterion
-        thunk = dev.STOP_FN(lambda ymin, ynext, gmin, gn, ndecmin, ndec, _u:
-                            1 if fn(ymin, ynext, gmin, np.array([gn]), None, ndecmin, ndec) else 0)
+
+        def _stop(ymin, ynext, gmin, gn, ndecmin, ndec, _u):
+            # ctypes would print and swallow an exception raised in here and return 0 ("not converged"); in the
+            # reference it propagates out of mgb_solve.  Keep the first one, end every Newton solve and the ramp
+            # at once, and let _run_core re-raise it.
+            if _pending(keep):
+                return 1
+            try:
+                return 1 if fn(ymin, ynext, gmin, np.array([gn]), None, ndecmin, ndec) else 0
+            except BaseException as e:          # noqa: BLE001 -- re-raised by _run_core
+                keep.append(_CallbackError(e))
+                return 1
+        thunk = dev.STOP_FN(_stop)
         keep.append(thunk)
         o.stopping_criterion = C.cast(thunk, C.c_void_p)
     elif stopping_criterion is not None:
@@ -128,16 +142,41 @@ def _options(P, tol, t, kappa, maxit, max_newton, line_search, stopping_criterio
         zn = P.nu * P.n
 
         def _early(zp, t, _u):
-            z = np.ctypeslib.as_array(zp, shape=(zn,)).copy()
-            return 1 if (early_stop_fn(z, t) if two else early_stop_fn(z)) else 0
+            if _pending(keep):
+                return 1
+            try:
+                z = np.ctypeslib.as_array(zp, shape=(zn,)).copy()
+                return 1 if (early_stop_fn(z, t) if two else early_stop_fn(z)) else 0
+            except BaseException as e:          # noqa: BLE001 -- re-raised by _run_core
+                keep.append(_CallbackError(e))
+                return 1
         thunk = dev.EARLY_FN(_early)
+        keep.append(thunk)
+        o.early_stop_fn = C.cast(thunk, C.c_void_p)
+    if callable(stopping_criterion) and not o.early_stop_fn:
+        # a raising stopping rule must also be able to end the t-ramp: a do-nothing early_stop that only reports it
+        thunk = dev.EARLY_FN(lambda zp, t, _u: 1 if _pending(keep) else 0)
         keep.append(thunk)
         o.early_stop_fn = C.cast(thunk, C.c_void_p)
     return o
 
 
+class _CallbackError:
+    """An exception raised inside a user callable while the library was running it."""
+
+    def __init__(self, exc):
+        self.exc = exc
+
+
+def _pending(keep):
+    return any(isinstance(k, _CallbackError) for k in keep)
+
+
 def _run_core(P, z, c, opt, what):
     status, znew, diag = P.mgb_core(z, c, opt, cap_steps=max(64, min(int(opt.maxit), 4096)))
+    for k in getattr(opt, "_keep", None) or []:
+        if isinstance(k, _CallbackError):          # a user callable raised: propagate like the reference would
+            raise k.exc
     diag["z"] = znew
     if status == ERR_CONVERGENCE:
         code = "iteration_limit" if diag["failure_code"] == 2 else "stall"

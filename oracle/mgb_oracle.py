@@ -517,6 +517,8 @@ def newton(F0, F1, F2, x, maxit=10000, stopping_criterion=None, line_search=None
         if not np.all(np.isfinite(n)):
             raise FloatingPointError("newton: Newton direction has non-finite entries")
         inc = float(np.dot(g, n))
+        if stats is not None and "trace" in stats:          # test instrumentation: full-length logs (tests/dev/)
+            stats["trace"](k, y, inc, H, g, n)
         if inc <= 0:
             converged = abs(inc) <= EPS * max(abs(y), 1.0)
             break

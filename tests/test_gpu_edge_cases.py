@@ -215,3 +215,33 @@ def test_four_piece_intersection_max_pieces():
     with pytest.raises(ValueError):                       # a fifth piece exceeds this build
         Q5 = m.intersect(mg, Q, one(1.0, 9.0))
         dev.DeviceMGBProblem(m.assemble(mg, Q=Q5))
+
+
+def test_exception_in_user_callable_propagates_and_vectors_outlive_nothing():
+    """A user `stopping_criterion` / `early_stop` that raises must surface from mgb_solve as in the reference
+    (its exception propagates out of newton, src/newton.jl:273), not be swallowed by the ctypes thunk; and a
+    DeviceVector collected after its context was closed must not touch the freed context."""
+    prob = _small_problem()
+    calls = {"n": 0}
+
+    def bad_stop(*a):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise ValueError("user stopping rule failed")
+        return False
+    with pytest.raises(ValueError, match="user stopping rule failed"):
+        m.mgb_solve(prob, stopping_criterion=bad_stop)
+    assert calls["n"] == 3                                     # nothing called it again after the failure
+
+    def bad_early(z):
+        raise KeyError("user early_stop failed")
+    with pytest.raises(KeyError):
+        m.mgb_solve(prob, early_stop=bad_early)
+    sol = m.mgb_solve(prob)                                    # the library is usable afterwards
+    assert np.isfinite(sol.z).all()
+    D = dev.DeviceMGBProblem(prob)
+    v = D.main.vec(np.ones(D.main.level_sizes[0]))
+    w = v + v                                                  # temporaries are DeviceVectors too
+    D.close()
+    assert v.handle is None and w.handle is None               # closed with their context
+    del v, w                                                   # __del__ after the context is gone: no native call

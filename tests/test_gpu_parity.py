@@ -335,6 +335,34 @@ def test_config3_full_size_properties():
     _full_size_properties(prob, 1e-5)
 
 
+def test_config3_default_hierarchy_end_to_end_solve():
+    """BASELINE configs[2] exactly as the bench runs it: fem2d_P2 p = 1.0, L = 9 on the reference-default ladder
+    amg(subdivide(fem2d_P2(), 9)) = amg_ruge_stuben(max_coarse=2) (src/fem2d_P2.jl:401).  No oracle run at 917 504
+    nodes; checked by invariants: the ladder is the pinned one, the solve converges with the pinned iteration count,
+    the result is strictly inside the cone at every node, Dirichlet data g = (x^2 + y^2, .) is reproduced exactly,
+    and a second solve on the resident image is bitwise identical with equal iteration counts."""
+    from mgb_amd.solve import mgb_driver
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 9)), p=1.0)
+    n = prob.M[0].w.size
+    assert n == 917504
+    assert [R.shape[1] for R in prob.M[0].R_fine] == [2, 7, 18, 66, 262, 1019, 4083, 16384, 65536, 131074, 1309697]
+    sol = m.mgb_solve(prob, keep_device=True)
+    try:
+        assert sol.SOL_feasibility is None                                        # the default start is feasible for p = 1
+        its = int(sol.SOL_main["its"].sum())
+        assert 500 <= its <= 580, its                                             # 537-548 in rounds 2-3 (DESIGN.md section 6)
+        assert sol.SOL_main["ts"][-1] >= 1.0 / np.sqrt(np.finfo(float).eps)      # the ramp reached 1/tol
+        F = sol.device.main.node_barrier(stacked(sol.z))
+        assert np.all(np.isfinite(F))                                             # strictly feasible everywhere
+        bnd = np.array([v + e * 7 for (v, e) in m.find_boundary(prob.geometry)])
+        assert bnd.size > 0 and np.array_equal(sol.z[bnd, 0], prob.g[bnd, 0])     # Dirichlet data exact
+        again = mgb_driver(sol.device)
+        assert np.array_equal(again["z"], sol.z)                                  # bitwise repeatable
+        assert np.array_equal(again["SOL_main"]["its"], sol.SOL_main["its"])
+    finally:
+        sol.device.close()
+
+
 def test_config4_full_size_properties():
     """fem3d Q1 p=4 L=6 (BASELINE configs[3] at full size: 262 144 nodes), on one GPU; the
     default start is infeasible there, so the properties are probed from a lifted slack."""
@@ -617,6 +645,18 @@ def test_reference_cuda_extension_cases_device_vs_cpu(name):
     ref = O.mgb_solve(prob)
     assert np.abs(sol.z - ref["z"]).max() < 1e-8                        # the reference's criterion (test/test_cuda.jl:51)
     assert "mgb_solve: device = HIPDevice" in sol.log
+
+
+def test_config0_fem1d_p2_L6_device_vs_oracle():
+    """BASELINE configs[0]: fem1d() p = 2, L = 6 (32 elements): device vs the CPU oracle at the reference's
+    cross-backend criterion (test/test_cuda.jl:51), on the AMG and on the geometric ladder."""
+    for mg in (m.amg(m.subdivide(m.fem1d(), 6)), m.geometric_mg(m.fem1d(), 6)):
+        prob = m.assemble(mg, p=2.0)
+        assert prob.M[0].w.size == 64 and prob.M[0].R_fine[-1].shape[1] == 95
+        sol = m.mgb_solve(prob)
+        ref = O.mgb_solve(prob)
+        assert np.abs(sol.z - ref["z"]).max() < 1e-8
+        _same_iteration_counts(sol.SOL_main["its"], ref["SOL_main"]["its"])
 
 
 def test_config4_default_start_phase1_full_size():

@@ -1,0 +1,57 @@
+"""The device LDL' against arbitrary matrices on the levels' patterns (mgbhip_set_hessian): backward error of both
+solve paths on graded (ill-conditioned) SPD matrices, and an A/B of the kernel families that are gated by system
+size -- the one-wave-per-front kernel and the inverse-based large-front path -- against the blocked / substitution
+kernels on the same plans and values (a size gate must not hide a kernel bug).
+
+Reference behaviour: `solve(symmetric(H), g)` = CHOLMOD, backward stable (src/utils.jl:142-145)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from solver_cases import CASES, build, key_of, matrices
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dev", "solver_ab_worker.py")
+ETA_MAX = 4e-12        # componentwise backward error (Oettli-Prager) accepted from an LDL' in fp64
+
+
+def _run(tmp_path, name, env):
+    out = str(tmp_path / f"{name}.npz")
+    e = dict(os.environ)
+    e.update(env)
+    subprocess.run([sys.executable, WORKER, out], check=True, env=e, cwd=ROOT, timeout=900)
+    return dict(np.load(out))
+
+
+def test_both_solve_paths_are_backward_stable_and_gated_kernels_agree(tmp_path):
+    from mgb_amd.device import DeviceMGBProblem
+    runs = {"default": _run(tmp_path, "default", {}),                                             # size gates as shipped
+            "fast": _run(tmp_path, "fast", {"MGBHIP_WAVE_MIN_N": "0", "MGBHIP_INV_MIN_N": "0"}),   # gated kernels everywhere
+            "slow": _run(tmp_path, "slow", {"MGBHIP_NO_WAVE_SMALL": "1", "MGBHIP_OLD_BIG": "1"})}  # nowhere
+    assert runs["default"].keys() == runs["fast"].keys() == runs["slow"].keys()
+    worst = {k: (0.0, "") for k in runs}
+    for fam, L, p, rs in CASES:
+        D = DeviceMGBProblem(build(fam, L, p, rs))
+        try:
+            for lev, grade, A, g in matrices(D.main):
+                key = key_of(fam, L, p, rs, lev, grade)
+                absA = abs(A)
+                for tag, res in runs.items():
+                    for suffix in ("_x", "_xn"):
+                        x = res[key + suffix]
+                        assert np.isfinite(x).all(), (tag, key, suffix)
+                        eta = float(np.max(np.abs(A @ x - g) / (absA @ np.abs(x) + np.abs(g))))
+                        if eta > worst[tag][0]:
+                            worst[tag] = (eta, key + suffix)
+                        assert eta <= ETA_MAX, (tag, key, suffix, eta)
+                    assert res[key + "_lam"][1] == 0.0, (tag, key)                               # no pivot flagged
+                    lam_ref = float(g @ res[key + "_x"])
+                    assert abs(res[key + "_lam"][0] - lam_ref) <= 1e-9 * abs(lam_ref), (tag, key)
+        finally:
+            D.close()
+    print("worst componentwise backward error per kernel selection:", {k: (f"{v[0]:.2e}", v[1]) for k, v in worst.items()})

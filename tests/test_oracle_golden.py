@@ -133,3 +133,31 @@ def test_host_multifrontal_matches_superlu():
         x1, x2 = mf(H, g), O.solve_symmetric(H, g)
         assert np.linalg.norm(x1 - x2) <= 1e-10 * np.linalg.norm(x2)
     mf.close()
+
+
+def test_config0_fem1d_p2_L6_oracle_properties():
+    """BASELINE.json configs[0]: fem1d() p = 2, L = 6 (32 elements, 64 broken nodes, 95 fine unknowns;
+    SURVEY.md section 8 size table).  No golden exists at this size; pinned through what the reference's tests
+    require of every size: all prolongator factories and the geometric ladder reach the same z
+    (test/test_algebraic.jl:24-31), Dirichlet data g = (x, 2) is reproduced exactly on the boundary, the
+    result is strictly feasible, and -- p = 2 makes the problem a 1-D Laplace-type problem with a smooth
+    symmetric solution -- u(x) - x is even."""
+    geom = m.subdivide(m.fem1d(), 6)
+    assert geom.t.shape[1] == 32 and geom.w.size == 64
+    prob = m.assemble(m.amg(geom), p=2.0)
+    assert prob.M[0].R_fine[-1].shape[1] == 95
+    sol = O.mgb_solve(prob)
+    z = sol["z"]
+    assert np.isfinite(z).all()
+    x = prob.M[0].x[:, 0]                                                        # broken-node order: node v of element e = v + 2e
+    bnd = [v + 2 * e for (v, e) in m.find_boundary(geom)]
+    assert sorted(x[bnd]) == [-1.0, 1.0] and np.array_equal(z[bnd, 0], x[bnd])     # Dirichlet data of g = (x, 2)
+    ze, xe = z.reshape(32, 2, 2), x.reshape(32, 2)
+    ux = (ze[:, 1, 0] - ze[:, 0, 0]) / (xe[:, 1] - xe[:, 0])
+    assert np.all(ze[:, :, 1] > (ux ** 2)[:, None])                              # strictly inside the cone s >= |u'|^p, p = 2
+    sa = O.mgb_solve(m.assemble(m.amg(geom, prolongator=m.amg_smoothed_aggregation(max_coarse=2)), p=2.0))
+    ge = O.mgb_solve(m.assemble(m.geometric_mg(m.fem1d(), 6), p=2.0))
+    assert np.linalg.norm(sa["z"] - z) < 1e-6 and np.linalg.norm(ge["z"] - z) < 1e-6
+    order = np.argsort(x, kind="stable")
+    dev = (z[:, 0] - x)[order]
+    assert np.abs(dev - dev[::-1]).max() < 1e-6
