@@ -191,6 +191,12 @@ int mgbhip_set_hessian(mgbhip_problem* prob, int32_t level, const double* values
  * [H -g; -g' -1] is factored, so the forward substitution rides along the factorization, and one backward
  * sweep returns x = H^{-1} g; lambda2 (optional) = <g, x>.                                                  */
 int mgbhip_solve_newton(mgbhip_problem* prob, int32_t level, const double* g, double* x, double* lambda2);
+/* One Newton direction exactly as the resident loop forms it at (s, c, z0): g = f1, H = f2 left in the
+ * element-block slab (fine levels: leaf fronts condensed inside the element kernel from the second call on),
+ * bordered factorization, backward sweep.  x = H^{-1} g, lambda2 = <g, x>; *condensed (optional) reports
+ * whether the element kernel wrote the leaf fronts.  Test / measurement hook.                               */
+int mgbhip_newton_direction(mgbhip_problem* prob, int32_t level, const double* s, const double* c,
+                            const double* z0, double* x, double* lambda2, int32_t* condensed);
 /* Per-node barrier value map_rows_gpu(F0, args..., Dz(z)) (src/mgb.jl:410-420) and the
  * slack initialiser (src/mgb.jl:437-440); y is n x nD column-major.                      */
 int mgbhip_node_barrier(mgbhip_problem* prob, const double* z, double* F /* n */, double* Dz /* n*nD or NULL */);

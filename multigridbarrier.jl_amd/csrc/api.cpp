@@ -256,6 +256,35 @@ int mgbhip_solve_newton(mgbhip_problem* P, int32_t level, const double* g, doubl
     MGB_API_END
 }
 
+int mgbhip_newton_direction(mgbhip_problem* P, int32_t level, const double* s, const double* c, const double* z0, double* x,
+                            double* lambda2, int32_t* condensed) {
+    MGB_API_BEGIN_ON(P)
+    check_level(P, level);
+    MGB_REQUIRE(s && c && z0 && x, "null argument");
+    hipStream_t st = P->stream();
+    const size_t m = (size_t)P->levels[level].m;
+    stage_inputs(P, level, s, c, z0);
+    P->eval_f1(level, P->d_x.p, P->d_z0.p, P->d_c.p, P->d_g.p);
+    P->eval_f2(level, P->d_x.p, P->d_z0.p, P->d_c.p, false, P->d_g.p);      // exactly the Newton loop's sequence
+    if (condensed) *condensed = P->levels[level].H_condensed ? 1 : 0;
+    P->factor(level, P->d_g.p);
+    P->trisolve_carried(level, P->d_nv.p);
+    const int status = P->levels[level].solver.status(st);
+    P->d_nv.download(x, m, st);
+    if (lambda2) {
+        std::vector<double> g(m);
+        P->d_g.download(g.data(), m, st);
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
+        double acc = 0.0;
+        for (size_t i = 0; i < m; ++i) acc += g[i] * x[i];
+        *lambda2 = acc;
+    }
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (status != MGBHIP_OK) g_last_error = "Cholesky met a non-positive pivot";
+    return status;
+    MGB_API_END
+}
+
 
 // ---- device-resident vectors --------------------------------------------------------------------
 static double* vec_scratch(mgbhip_ctx* c, int64_t len) {

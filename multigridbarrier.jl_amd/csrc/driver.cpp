@@ -72,7 +72,9 @@ struct NewtonCtx {
     int64_t m;
     double F0(const double* d_s) { return P->eval_f0(level, d_s, d_zJ, d_c); }
     void F1(const double* d_s, double* d_out) { P->eval_f1(level, d_s, d_zJ, d_c, d_out); }
-    void F2(const double* d_s) { P->eval_f2(level, d_s, d_zJ, d_c, false); }   // H stays in the slab where the level allows
+    // H stays in the slab where the level allows; g (the right-hand side of the solve that follows) lets the fine level
+    // condense the element-local unknowns inside the element kernel
+    void F2(const double* d_s) { P->eval_f2(level, d_s, d_zJ, d_c, false, P->d_g.p); }
 };
 
 // One line-search trial shared by both searches: evaluates F0/F1 at xn (already formed in
@@ -206,7 +208,7 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
             MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
             L.solver.status_async(P->pin.i + 1, st);
             MGB_HIP_CHECK(hipStreamSynchronize(st));
-            fstatus = MfSolver::status_from(P->pin.i[1]);
+            fstatus = MfSolver::status_from(P->pin.i + 1, L.solver.factored_condensed);
             // The fast large-front kernels apply inverted 32 x 32 diagonal blocks; near the edge of singularity
             // that loses digits a substitution keeps.  A failed pivot, a non-finite direction or lambda^2 <= 0
             // is re-done once with the substitution kernels before the reference's own tests see it.

@@ -297,7 +297,7 @@ struct SigDefault {
     static __device__ __forceinline__ constexpr int mask() { return ((1 << NY) - 1) & ~1; }
 };
 
-template <int NY, int P, class Sig>
+template <int NY, int P, class Sig, bool CONDENSE = false>
 __global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
     constexpr int G = (P <= 2) ? 2 : (P <= 4) ? 4 : (P <= 8) ? 8 : (P <= 16) ? 16 : (P <= 32) ? 32 : 64;
     constexpr int EPB = 256 / G;
@@ -380,14 +380,16 @@ __global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
     const int j = r;
     const double* Ye = YL + (size_t)el * NT * G;
     int blk = 0;
+    double cblk[CONDENSE ? 3 : 1][P];      // CONDENSE: column j of the uu / us blocks and ss_j stay in registers
 #pragma unroll
     for (int a = 0; a < nu; ++a)
 #pragma unroll
         for (int b = a; b < nu; ++b, ++blk) {
             // lane j owns column j of the block: P contiguous doubles of the block-major slab; a wave
             // covers 64/G whole blocks, so every cache line is completed within the wave's stores
-            const bool dblk = (Pm.diag_mask >> blk) & 1;      // diagonal block, stored compactly
-            double* dst = Pm.out_hel + Pm.blk_off[blk] + (dblk ? (e * P + j) : (e * P + j) * (int64_t)P);
+            const bool dblk = CONDENSE ? (blk == 2) : ((Pm.diag_mask >> blk) & 1);      // diagonal block, stored compactly
+            double* dst = CONDENSE ? &cblk[blk < 3 ? blk : 0][0]
+                                   : Pm.out_hel + Pm.blk_off[blk] + (dblk ? (e * P + j) : (e * P + j) * (int64_t)P);
             bool b_all_id = true;
 #pragma unroll
             for (int k2 = 0; k2 < NY; ++k2)
@@ -464,6 +466,105 @@ __global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
                 }
             }
         }
+    if constexpr (CONDENSE) {
+        // ---- partial factorization of the element's leaf front (kernels.hpp: launch_elem_f2_condense) --------------
+        // Leaf index list: [slack of node 0..P-1 | interior u node (element node P-1) | the other element nodes that
+        // are unknowns, in the front's order | border].  Lane j holds uu(:, j), us(:, j) (u_i against slack j), ss_j.
+        static_assert(!Sig::rt && P <= 8, "condensation: default two-state signature only");
+        constexpr int PB = P - 1;                     // the interior node
+        __syncthreads();                              // every lane is done with the staged operators: reuse their LDS
+        double* X = opL + (size_t)el * (2 * PP);      // per-element scratch (nstage == 2: 2 * PP doubles per element)
+        double* Xus = X;                              // [P][P]: Xus[q * P + i] = us(i, q)
+        double* Xinv = X + PP;                        // [P] 1 / ss_q
+        double* Xbeta = Xinv + P;                     // [P] border entries -g of the slacks
+        double* Xc = Xbeta + P;                       // [P] uu'(:, PB) after the slack elimination
+        double* Xs = Xc + P;                          // [0] border entry of the interior node after the slacks, [1] its pivot
+        const double* uuc = cblk[0];
+        const double* usc = cblk[1];
+        const double ssj = cblk[2][0];
+        LeafDesc ld{0, 0, 0};
+        double inv = 0.0, beta = 0.0;
+        bool bad = false;
+        if (active) {
+            ld = Pm.leaf_desc[e];
+            beta = -Pm.leaf_g[Pm.leaf_slack0 + node];
+            bad = (ssj == 0.0) || !isfinite(ssj);
+            inv = 1.0 / ssj;
+#pragma unroll
+            for (int i = 0; i < P; ++i) Xus[j * P + i] = usc[i];
+            Xinv[j] = inv;
+            Xbeta[j] = beta;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double up[P];                                 // uu'(i, j) = uu(i, j) - sum_q us(i, q) us(j, q) / ss_q
+        double bj = 0.0, corner = 0.0;
+        if (active) {
+            double t[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) t[q] = Xus[q * P + j] * Xinv[q];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                double acc = uuc[i];
+#pragma unroll
+                for (int q = 0; q < P; ++q) acc -= Xus[q * P + i] * t[q];
+                up[i] = acc;
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q) bj -= Xbeta[q] * t[q];                 // border row entry of u_j after the slacks
+            if (j == PB) {
+                bj -= Pm.leaf_g[ld.interior];                                   // the interior node is a pivot of this leaf
+#pragma unroll
+                for (int q = 0; q < P; ++q) corner -= Xbeta[q] * Xbeta[q] * Xinv[q];
+#pragma unroll
+                for (int i = 0; i < P; ++i) Xc[i] = up[i];
+                Xs[0] = bj;
+                Xs[1] = up[PB];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (active) {
+            const int m = (int)(ld.packed & 15u);
+            double* Fg = Pm.leaf_arena + ld.F_off;
+            int pos[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) pos[i] = (int)((ld.packed >> (4 + 4 * i)) & 15u);
+            const double d7 = Xs[1], bb = Xs[0];
+            const double inv7 = 1.0 / d7;
+            bad = bad || (j == PB && ((d7 == 0.0) || !isfinite(d7)));
+            // slack column j: pivot, zeros against the later slacks, the u rows, the border row
+            double* Cj = Fg + (size_t)j * m;
+            Cj[j] = ssj;
+#pragma unroll
+            for (int rr = 0; rr < P; ++rr)
+                if (rr > j) Cj[rr] = 0.0;
+            Cj[P] = usc[PB] * inv;
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                if (pos[i] != 15) Cj[pos[i]] = usc[i] * inv;
+            Cj[m - 1] = beta * inv;
+            if (j == PB) {                             // column of the interior node
+                double* Cb = Fg + (size_t)P * m;
+                Cb[P] = d7;
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    if (pos[i] != 15) Cb[pos[i]] = Xc[i] * inv7;
+                Cb[m - 1] = bb * inv7;
+                Fg[(size_t)(m - 1) * m + (m - 1)] = corner - bb * bb * inv7;
+            } else if (pos[j] != 15) {                 // update column of element node j
+                const double f = Xc[j] * inv7;
+                double* Cu = Fg + (size_t)pos[j] * m;
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    if (pos[i] != 15 && pos[i] >= pos[j]) Cu[pos[i]] = up[i] - Xc[i] * f;
+                Cu[m - 1] = bj - bb * f;
+            }
+        }
+        if (bad) atomicOr(Pm.leaf_status, 1);
+    }
 }
 
 // Specialised line-search trial (MODE_F01 of the generic kernel: value and gradient at one point from one
@@ -1229,6 +1330,27 @@ static bool try_f2_fast(const ElemParams& P, hipStream_t st) {
         hipLaunchKernelGGL((elem_f2_fast<NY, PN, SigDefault<NY>>), dim3((unsigned)elem_grid(PN, P.N)), dim3(256), lds, st, P);
     else
         hipLaunchKernelGGL((elem_f2_fast<NY, PN, SigRuntime>), dim3((unsigned)elem_grid(PN, P.N)), dim3(256), lds, st, P);
+    return true;
+}
+
+bool launch_elem_f2_condense(const ElemParams& P, hipStream_t st) {
+    // fem2d_P2 with bubble, default D table: 7 nodes per element, node 6 interior (the only family specialised so far)
+    constexpr int NY = 4, PN = 7;
+    if (P.nD != NY || P.p != PN || P.nu != 2 || P.nstage != 2 || !is_default_signature<NY>(P)) return false;
+    for (int k = 0; k < NY; ++k)
+        if (P.D_stage[k] == -2) return false;
+    MGB_REQUIRE(P.leaf_desc && P.leaf_arena && P.leaf_g && P.leaf_status, "condensing f2: leaf arguments missing");
+    const int G = elem_group(PN);
+    const int EPB = 256 / G;
+    const size_t lds = (256 * (size_t)P.nu + (size_t)P.nstage * EPB * PN * PN + (size_t)EPB * (NY * (NY + 1) / 2) * G) * sizeof(double);
+    static bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)elem_f2_fast<NY, PN, SigDefault<NY>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        return true;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL((elem_f2_fast<NY, PN, SigDefault<NY>, true>), dim3((unsigned)elem_grid(PN, P.N)), dim3(256), lds, st, P);
+    MGB_HIP_CHECK(hipGetLastError());
     return true;
 }
 

@@ -8,6 +8,13 @@ namespace mgbhip {
 enum ElemMode { MODE_F0 = 0, MODE_F1 = 1, MODE_F2 = 2, MODE_NODE_F = 3, MODE_NODE_SLACK = 4,
                 MODE_F01 = 5 };   // MODE_F01: value and gradient of one line-search trial in ONE pass over the operators
 
+// Where the leaf front of an element lives and how its boundary is ordered (built by MfSolver::enable_condensed).
+struct LeafDesc {
+    int64_t F_off;       // offset of the frontal matrix in the arena (column-major m x m)
+    int32_t interior;    // column (unknown id) of the element-interior u node
+    uint32_t packed;     // bits 0-3: m; bits 4+4i .. 7+4i: position of element node i in the front's index list, 15 = no unknown
+};
+
 struct ElemParams {
     int32_t p, nu, nD, nstage;
     int32_t ymask;                           // bit k set: row k of y enters some barrier term (else d/dy_k = 0)
@@ -32,7 +39,22 @@ struct ElemParams {
     int64_t blk_off[MGBHIP_MAX_NU * (MGBHIP_MAX_NU + 1) / 2];   // slab offset of every element block
     double* dn_Dz;                           // dense path (p > 64, N = 1): n x nD workspace for D*z
     double* dn_Y;                            // dense path: n x nD (f1) / n x nD(nD+1)/2 (f2) node weights
+    // condensing f2 (launch_elem_f2_condense): the element kernel eliminates the element-local unknowns itself
+    const LeafDesc* leaf_desc;               // one per element
+    double* leaf_arena;                      // the solver's frontal arena
+    const double* leaf_g;                    // gradient in level coefficients (the border column is -g)
+    int64_t leaf_slack0;                     // column of the slack unknown of broken node 0 (slack of node i = leaf_slack0 + i)
+    int32_t* leaf_status;                    // |= 1 on a zero / non-finite pivot
 };
+
+// Fine-level Newton systems: H of the default problem couples the p broken slack unknowns of an element (diagonal
+// H_ss because D_s = id) and its interior u unknown (the bubble) to the element's own nodes only -- the leaf fronts of
+// the elimination tree (mf_analysis.hpp, simplicial peeling) are one per element.  launch_elem_f2_condense computes the
+// element blocks like MODE_F2 and performs that leaf's partial factorization in place (static condensation of slacks
+// and bubble, with the border row of the bordered system [H -g; -g' -1]), writing the leaf front -- L panel, pivots,
+// update block -- straight into the solver's arena: the element blocks never reach HBM, the leaf level of the
+// factorization and the shared-entry sums of the assembly disappear.  Returns false when no specialisation applies.
+bool launch_elem_f2_condense(const ElemParams& P, hipStream_t st);
 
 // element Hessian slab layout: block-major [block][element][p*p]; blocks (a,b), a <= b, in
 // row-major order of the upper block triangle, each p x p column-major.

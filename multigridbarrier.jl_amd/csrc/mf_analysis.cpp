@@ -31,6 +31,7 @@ struct Builder {
     std::vector<char> removed;      // ordered already
     std::vector<std::vector<int32_t>> sn_piv;
     int32_t next_pos = 0;
+    int32_t sn_round2_end = 0;      // supernodes [0, sn_round2_end) come from the first two peeling rounds
 
     // scratch for the dissection
     std::vector<int32_t> tag;       // subset membership id
@@ -124,6 +125,7 @@ struct Builder {
             }
             // removal happens after grouping so that `removed` is stable during same_nb
             for (auto& grp : groups) new_supernode(grp.data(), grp.size());
+            if (round == 1) sn_round2_end = (int32_t)sn_piv.size();
             plan.peeled += (int64_t)chosen.size();
             plan.peel_rounds = round + 1;
         }
@@ -296,6 +298,9 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
     b.dim = dim;
 
     b.peel(plan);
+    // supernodes [0, nsn_peeled) are the element-local unknowns (round 1: the broken slacks, round 2: the element-
+    // interior nodes they expose); later rounds peel ordinary mesh nodes
+    const int32_t nsn_peeled = b.sn_round2_end;
     {
         std::vector<int32_t> rest;
         for (int32_t v = 0; v < n; ++v)
@@ -347,6 +352,7 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
             const int64_t merged_m = ks + (int64_t)b.sn_piv[f].size() + (int64_t)sn_struct[f].size();
             const bool relaxed = opt.merge_max_m > 0 && merged_m <= opt.merge_max_m;
             if (!exact && !relaxed) continue;
+            if (opt.protect_peeled && s < nsn_peeled && f >= nsn_peeled) continue;
             // an exact fit costs no flops, but merging a large child serialises two pivot chains that
             // the tree would run side by side (the half-domain separator into the root separator):
             // only fronts that stay within one LDS workgroup are amalgamated

@@ -71,6 +71,10 @@ struct MfOptions {
     // bordered system is block diagonal and ordinary solves are unchanged.  Values of the border column are read
     // from the tail of the value array: entry (v, n) at nnz + v, entry (n, n) at nnz + n.
     bool border = false;
+    // Keep fronts made of peeled unknowns apart from the dissection fronts above them (no exact-fit amalgamation
+    // across that line): on fine levels the peeled fronts are then exactly the per-element static-condensation leaves
+    // the condensing element kernel writes (MfSolver::enable_condensed).
+    bool protect_peeled = false;
 };
 
 // Symmetric pattern in CSR (both triangles present, diagonal optional).  Values are not

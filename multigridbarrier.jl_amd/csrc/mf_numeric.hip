@@ -2145,8 +2145,9 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __res
 }  // namespace
 
 void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st,
-                       const double* coords, int dim) {
+                       const double* coords, int dim, bool protect_peeled) {
     MfOptions opt;
+    opt.protect_peeled = protect_peeled;
     // tuning overrides (defaults are the measured best on MI355X)
     if (const char* e = getenv("MGBHIP_LEAF")) opt.leaf_size = atoi(e);
     if (const char* e = getenv("MGBHIP_SEPW")) opt.sep_weight = atof(e);
@@ -2160,35 +2161,6 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
         const Front& f = plan.fronts[i];
         fd[i] = FrontDev{f.k, f.m, f.nchild, f.a_cnt, f.F_off, f.idx_off, f.u_off, f.child_off, f.rel_off, f.a_off, f.acol_off, -1};
     }
-    // update-vector gather lists of the large fronts (forward solve): for every local index the entries of
-    // the children's update vectors that land on it, in child order (the summation order of the extend-add)
-    std::vector<int64_t> ug_ptr, ug_src;
-    for (int32_t i = 0; i < nf; ++i) {
-        const Front& f = plan.fronts[i];
-        if (f.m <= 128) continue;
-        fd[i].ug_off = (int64_t)ug_ptr.size();
-        std::vector<int32_t> cnt((size_t)f.m + 1, 0);
-        for (int32_t c = 0; c < f.nchild; ++c) {
-            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
-            for (int32_t j = 0; j < ch.m - ch.k; ++j) cnt[plan.rel[ch.rel_off + j] + 1]++;
-        }
-        const int64_t base = (int64_t)ug_src.size();
-        std::vector<int64_t> pos((size_t)f.m + 1);
-        pos[0] = base;
-        for (int32_t j = 0; j < f.m; ++j) pos[j + 1] = pos[j] + cnt[j + 1];
-        ug_ptr.insert(ug_ptr.end(), pos.begin(), pos.end());
-        ug_src.resize((size_t)pos[f.m]);
-        std::vector<int64_t> fill(pos.begin(), pos.end() - 1);
-        for (int32_t c = 0; c < f.nchild; ++c) {
-            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
-            for (int32_t j = 0; j < ch.m - ch.k; ++j) ug_src[(size_t)fill[plan.rel[ch.rel_off + j]]++] = ch.u_off + j;
-        }
-    }
-    if (ug_ptr.empty()) ug_ptr.push_back(0);
-    if (ug_src.empty()) ug_src.push_back(0);
-    d_ug_ptr.upload(ug_ptr, st);
-    d_ug_src.upload(ug_src, st);
-    d_fronts.upload(fd, st);
     d_front_idx.upload(plan.front_idx, st);
     d_children.upload(plan.children, st);
     d_rel.upload(plan.rel, st);
@@ -2208,7 +2180,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     d_tbig.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
     d_tsol.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
     d_dvec.alloc(plan.front_idx.size() ? plan.front_idx.size() : 1);
-    d_status.alloc(1);
+    d_status.alloc(2);           // [0] factorization, [1] leaf pivots of a condensing f2
     d_status.zero(st);
 
     // dynamic LDS above 64 KB needs an explicit opt-in; fall back to the 64 KB classes if refused
@@ -2307,6 +2279,41 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             }
         }
     }
+    std::vector<char> on_big_path((size_t)nf, 0);       // fronts of the large-front launches (after the merges above)
+    for (auto& lev : level_launches)
+        for (auto& L : lev)
+            if (!L.cls)
+                for (int32_t q = L.first; q < L.first + L.count; ++q) on_big_path[q] = 1;
+    // update-vector gather lists of the large fronts (forward solve): for every local index the entries of
+    // the children's update vectors that land on it, in child order (the summation order of the extend-add)
+    std::vector<int64_t> ug_ptr, ug_src;
+    for (int32_t i = 0; i < nf; ++i) {
+        const Front& f = plan.fronts[i];
+        if (!on_big_path[i]) continue;
+        fd[i].ug_off = (int64_t)ug_ptr.size();
+        std::vector<int32_t> cnt((size_t)f.m + 1, 0);
+        for (int32_t c = 0; c < f.nchild; ++c) {
+            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
+            for (int32_t j = 0; j < ch.m - ch.k; ++j) cnt[plan.rel[ch.rel_off + j] + 1]++;
+        }
+        const int64_t base = (int64_t)ug_src.size();
+        std::vector<int64_t> pos((size_t)f.m + 1);
+        pos[0] = base;
+        for (int32_t j = 0; j < f.m; ++j) pos[j + 1] = pos[j] + cnt[j + 1];
+        ug_ptr.insert(ug_ptr.end(), pos.begin(), pos.end());
+        ug_src.resize((size_t)pos[f.m]);
+        std::vector<int64_t> fill(pos.begin(), pos.end() - 1);
+        for (int32_t c = 0; c < f.nchild; ++c) {
+            const Front& ch = plan.fronts[plan.children[f.child_off + c]];
+            for (int32_t j = 0; j < ch.m - ch.k; ++j) ug_src[(size_t)fill[plan.rel[ch.rel_off + j]]++] = ch.u_off + j;
+        }
+    }
+    if (ug_ptr.empty()) ug_ptr.push_back(0);
+    if (ug_src.empty()) ug_src.push_back(0);
+    d_ug_ptr.upload(ug_ptr, st);
+    d_ug_src.upload(ug_src, st);
+    d_fronts.upload(fd, st);
+    h_fronts = fd;
     {   // Packed LDS triangles.  Leaf fronts with m <= 16 (mf_factor_tiny) scatter A with column stride 16: 136 LDS
         // doubles per front instead of 256, which doubles the resident workgroups of that kernel.  Launches of fronts
         // with m <= 48 whose children are all small (update block <= 8 x 8: the element leaves under a level-1
@@ -2343,6 +2350,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             }
         d_a_dst.upload(ad, st);
         MGB_HIP_CHECK(hipStreamSynchronize(st));
+        h_a_dst.swap(ad);
     }
     // the wave-per-front solve kernels do not depend on the LDS class: one launch per level
     level_solves.assign(nlev, {});
@@ -2393,12 +2401,12 @@ bool MfSolver::launch_big_assemble(const MfLaunch& L, dim3 ga, const double* d_v
     const size_t lds = (size_t)L.max_child * (size_t)L.max_m * sizeof(int32_t);
     if (L.max_child >= 1 && L.max_child <= GATHER_MAX_CHILD && lds <= 40 * 1024) {
         if (with_diag) ga.x += 1;          // the diagonal-block workgroup
-        hipLaunchKernelGGL(mf_big_gather, ga, dim3(256), lds, st, d_fronts.p, L.first, d_children.p, d_rel.p, a_src_p,
-                           d_a_dst.p, d_a_colptr.p, d_values, d_arena.p, L.max_m, d_dscr.p, d_status.p, with_diag ? 1 : 0);
+        hipLaunchKernelGGL(mf_big_gather, ga, dim3(256), lds, st, cur_fr, L.first, d_children.p, d_rel.p, a_src_p,
+                           cur_adst, cur_acol, d_values, d_arena.p, L.max_m, d_dscr.p, d_status.p, with_diag ? 1 : 0);
         return with_diag;
     } else
-        hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, d_fronts.p, L.first, d_children.p, d_rel.p, a_src_p,
-                           d_a_dst.p, d_a_colptr.p, d_values, d_arena.p);
+        hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, cur_fr, L.first, d_children.p, d_rel.p, a_src_p,
+                           cur_adst, cur_acol, d_values, d_arena.p);
     return false;
 }
 
@@ -2414,13 +2422,21 @@ void MfSolver::set_direct_map(const int32_t* value_map, int64_t nnz, int64_t tai
     MGB_HIP_CHECK(hipStreamSynchronize(st));
 }
 
-void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timers, bool direct) {
+void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timers, bool direct, bool condensed) {
     MGB_REQUIRE(!direct || d_a_src_direct.n > 0, "MfSolver::factor: no direct value map");
-    const int32_t* a_src_p = direct ? d_a_src_direct.p : d_a_src.p;
+    MGB_REQUIRE(!condensed || (direct && condensed_ok), "MfSolver::factor: condensed leaves are not enabled");
+    // condensed: the leaf fronts were written by the element kernel (kernels.hpp, launch_elem_f2_condense); the other
+    // fronts take only their border entries from the value array -- every element contribution reaches them through
+    // the leaves' update blocks
+    const int32_t* a_src_p = condensed ? d_a_src_c.p : (direct ? d_a_src_direct.p : d_a_src.p);
+    cur_fr = condensed ? d_fronts_c.p : d_fronts.p;
+    cur_adst = condensed ? d_a_dst_c.p : d_a_dst.p;
+    cur_acol = condensed ? d_a_colptr_c.p : d_a_colptr.p;
     MGB_REQUIRE(analyzed, "MfSolver::factor before analyze");
     if (timers) timers->begin("factor");
     factored_inv = !robust;
-    d_status.zero(st);
+    MGB_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));      // [1], the leaf flag of a condensing f2, stays
+    factored_condensed = condensed;
     static const bool lvl_timing = [] { const char* e = getenv("MGBHIP_LEVEL_TIMING"); return e && e[0] == '1'; }();
     int lvno = -1;
     for (auto& lev : level_launches) {
@@ -2430,19 +2446,20 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
         StageScope lvscope(*timers_or_dummy(timers, lvl_timing), nm);
         for (auto& L : lev) {
             if (L.count == 0) continue;
+            if (condensed && lvno == 0) continue;          // written by the element kernel
             if (L.tiny) {
-                hipLaunchKernelGGL(mf_factor_tiny, dim3((L.count + 15) / 16), dim3(256), 0, st, d_fronts.p, L.first,
-                                   L.count, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                hipLaunchKernelGGL(mf_factor_tiny, dim3((L.count + 15) / 16), dim3(256), 0, st, cur_fr, L.first,
+                                   L.count, a_src_p, cur_adst, d_values, d_arena.p, d_status.p);
             } else if (L.wave) {
                 const dim3 gw((L.count + 3) / 4);
                 if (L.cls <= 32) {
                     const size_t lds = (size_t)4 * (32 * 33 / 2) * sizeof(double) + 4 * 128 * (sizeof(int64_t) + sizeof(int32_t));
-                    hipLaunchKernelGGL(mf_factor_wave<32>, gw, dim3(256), lds, st, d_fronts.p, L.first, L.count, d_children.p, d_rel.p,
-                                       a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                    hipLaunchKernelGGL(mf_factor_wave<32>, gw, dim3(256), lds, st, cur_fr, L.first, L.count, d_children.p, d_rel.p,
+                                       a_src_p, cur_adst, d_values, d_arena.p, d_status.p);
                 } else {
                     const size_t lds = (size_t)4 * (48 * 49 / 2) * sizeof(double) + 4 * 128 * (sizeof(int64_t) + sizeof(int32_t));
-                    hipLaunchKernelGGL(mf_factor_wave<48>, gw, dim3(256), lds, st, d_fronts.p, L.first, L.count, d_children.p, d_rel.p,
-                                       a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p);
+                    hipLaunchKernelGGL(mf_factor_wave<48>, gw, dim3(256), lds, st, cur_fr, L.first, L.count, d_children.p, d_rel.p,
+                                       a_src_p, cur_adst, d_values, d_arena.p, d_status.p);
                 }
             } else if (L.cls) {
                 static const int nbt_mid = [] { const char* e = getenv("MGBHIP_NBT"); return e ? atoi(e) : 8; }();
@@ -2453,8 +2470,8 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 const bool packed = L.cls >= 88;
                 const size_t lds = (size_t)((packed ? L.cls * (L.cls + 1) / 2 : L.cls * L.cls) + nbt_alloc * L.cls) * sizeof(double);    // front + scaled panel
 #define MGB_LAUNCH_SMALL(NBTV, PK)                                                                                          \
-    hipLaunchKernelGGL((mf_factor_small<NBTV, PK>), dim3(L.count), dim3(threads), lds, st, d_fronts.p, L.first, d_children.p, \
-                       d_rel.p, a_src_p, d_a_dst.p, d_values, d_arena.p, d_status.p)
+    hipLaunchKernelGGL((mf_factor_small<NBTV, PK>), dim3(L.count), dim3(threads), lds, st, cur_fr, L.first, d_children.p, \
+                       d_rel.p, a_src_p, cur_adst, d_values, d_arena.p, d_status.p)
                 if (nbt <= 8) { if (packed) MGB_LAUNCH_SMALL(8, true); else MGB_LAUNCH_SMALL(8, false); }
                 else if (nbt <= 16) { if (packed) MGB_LAUNCH_SMALL(16, true); else MGB_LAUNCH_SMALL(16, false); }
                 else { if (packed) MGB_LAUNCH_SMALL(32, true); else MGB_LAUNCH_SMALL(32, false); }
@@ -2466,13 +2483,13 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 const bool diag_done = launch_big_assemble(L, ga, d_values, a_src_p, st, true);
                 const bool pre_diag = diag_done || L.count >= 24;
                 if (pre_diag && !diag_done)
-                    hipLaunchKernelGGL(mf_big_diag0, dim3(L.count), dim3(256), 0, st, d_fronts.p, L.first, d_arena.p, d_dscr.p,
+                    hipLaunchKernelGGL(mf_big_diag0, dim3(L.count), dim3(256), 0, st, cur_fr, L.first, d_arena.p, d_dscr.p,
                                        d_status.p);
                 for (int j0 = 0; j0 < L.max_k; j0 += NB) {
                     const int rem = L.max_m - j0;
                     const int T = std::max(0, (rem - 1 + ST - 1) / ST);
                     const dim3 gs(T * (T + 1) / 2 + 1, L.count);         // trailing tiles + the look-ahead workgroup
-                    hipLaunchKernelGGL(mf_big_step, gs, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p, d_dscr.p,
+                    hipLaunchKernelGGL(mf_big_step, gs, dim3(256), 0, st, cur_fr, L.first, j0, d_arena.p, d_dscr.p,
                                        d_dvec.p, d_status.p, (j0 == 0 && !pre_diag) ? 1 : 0);
                 }
             } else {
@@ -2481,12 +2498,12 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 for (int j0 = 0; j0 < L.max_k; j0 += NB) {
                     const int rem = L.max_m - j0;                // rows from the panel start, at most
                     const dim3 gp(std::max(1, (rem - 1 + TR - 1) / TR), L.count);
-                    hipLaunchKernelGGL(mf_big_panel, gp, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p,
+                    hipLaunchKernelGGL(mf_big_panel, gp, dim3(256), 0, st, cur_fr, L.first, j0, d_arena.p,
                                        d_dscr.p, d_status.p, j0 == 0 ? 1 : 0);
                     const int T = (rem - 1 + ST - 1) / ST;       // trailing tiles (upper bound)
                     if (T > 0) {
                         const dim3 gu(T * (T + 1) / 2 + 1, L.count);     // + the look-ahead workgroup
-                        hipLaunchKernelGGL(mf_big_update, gu, dim3(256), 0, st, d_fronts.p, L.first, j0, d_arena.p,
+                        hipLaunchKernelGGL(mf_big_update, gu, dim3(256), 0, st, cur_fr, L.first, j0, d_arena.p,
                                            d_dscr.p, d_status.p);
                     }
                 }
@@ -2619,15 +2636,89 @@ void mf_debug_probe(long long* out64) {
 }
 #endif
 
-void MfSolver::status_async(int32_t* h_dst, hipStream_t st) const {
-    MGB_HIP_CHECK(hipMemcpyAsync(h_dst, d_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+void MfSolver::status_async(int32_t* h_dst2, hipStream_t st) const {
+    MGB_HIP_CHECK(hipMemcpyAsync(h_dst2, d_status.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
 }
 
 int MfSolver::status(hipStream_t st) {
-    int32_t h = 0;
-    d_status.download(&h, 1, st);
+    int32_t h[2] = {0, 0};
+    d_status.download(h, 2, st);
     MGB_HIP_CHECK(hipStreamSynchronize(st));
-    return h ? MGBHIP_ERR_NOT_SPD : MGBHIP_OK;
+    return status_from(h, factored_condensed);
+}
+
+// ---- condensed leaves ----------------------------------------------------------------------------------------
+bool MfSolver::enable_condensed(int64_t N, int P, const int32_t* ucol, int64_t slack0, int64_t nnz, int64_t tail_base,
+                                hipStream_t st) {
+    condensed_ok = false;
+    int why = 0;
+    struct Report { int& w; ~Report() { if (w) if (const char* e = getenv("MGBHIP_DEBUG"); e && atoi(e) >= 2) fprintf(stderr, "[mgbhip] condensed leaves: plan shape check %d failed\n", w); } } report{why};
+    const int32_t nlev = (int32_t)plan.level_ptr.size() - 1;
+    if (!analyzed || !plan.border || nlev < 2 || P > 7) { why = 1; return false; }
+    const int32_t n0 = plan.level_ptr[1];
+    if ((int64_t)n0 != N) { why = 2; return false; }
+    const int32_t nbor = (int32_t)plan.n;
+    std::vector<LeafDesc> desc((size_t)N);
+    std::vector<char> seen((size_t)N, 0);
+    for (int32_t i = 0; i < n0; ++i) {
+        const Front& f = plan.fronts[i];
+        const int32_t* idx = plan.front_idx.data() + f.idx_off;
+        if (f.k != P + 1 || f.m > 15 || f.nchild != 0 || idx[f.m - 1] != nbor) { why = 3; return false; }
+        const int64_t e = ((int64_t)idx[0] - slack0) / P;
+        if (e < 0 || e >= N || seen[(size_t)e]) { why = 4; return false; }
+        for (int q = 0; q < P; ++q)
+            if ((int64_t)idx[q] != slack0 + e * P + q) { why = 5; return false; }           // pivots: the element's slacks in node order ...
+        if (idx[P] != ucol[e * P + (P - 1)] || idx[P] < 0) { why = 6; return false; }       // ... then its interior u node
+        uint32_t packed = (uint32_t)f.m;
+        int found = 0;
+        for (int q = 0; q < P - 1; ++q) {
+            uint32_t pos = 15;
+            const int32_t c = ucol[e * P + q];
+            if (c >= 0)
+                for (int32_t t = P + 1; t < f.m - 1; ++t)
+                    if (idx[t] == c) { pos = (uint32_t)t; ++found; break; }
+            packed |= pos << (4 + 4 * q);
+        }
+        if (found != f.m - 1 - (P + 1)) { why = 7; return false; }                           // every boundary unknown is a node of the element
+        for (int q = 0; q < P - 1; ++q)                                          // ... and every node that is an unknown is on the boundary
+            if (ucol[e * P + q] >= 0 && ((packed >> (4 + 4 * q)) & 15u) == 15u) { why = 8; return false; }
+        packed |= 15u << (4 + 4 * (P - 1));
+        desc[(size_t)e] = LeafDesc{f.F_off, idx[P], packed};
+        seen[(size_t)e] = 1;
+    }
+    // A lists of the other fronts without the matrix entries (which arrive through the leaves): the border column only
+    const int32_t nf = (int32_t)plan.fronts.size();
+    std::vector<FrontDev> fd(h_fronts);
+    std::vector<int32_t> as, ad, ac;
+    for (int32_t i = 0; i < nf; ++i) {
+        const Front& f = plan.fronts[i];
+        fd[i].a_off = (int64_t)as.size();
+        fd[i].acol_off = (int64_t)ac.size();
+        const int32_t* cp = plan.a_colptr.data() + f.acol_off;
+        for (int32_t c = 0; c < f.k; ++c) {
+            ac.push_back((int32_t)((int64_t)as.size() - fd[i].a_off));
+            if (i < n0) continue;
+            for (int32_t t = cp[c]; t < cp[c + 1]; ++t) {
+                const int64_t src = plan.a_src[f.a_off + t];
+                if (src < nnz) continue;
+                const int64_t v = tail_base + (src - nnz);
+                if (v >= (int64_t)INT32_MAX) return false;
+                as.push_back((int32_t)v);
+                ad.push_back(h_a_dst[f.a_off + t]);
+            }
+        }
+        fd[i].a_cnt = (int32_t)((int64_t)as.size() - fd[i].a_off);
+        ac.push_back(fd[i].a_cnt);
+    }
+    if (as.empty()) { as.push_back(0); ad.push_back(0); }
+    d_fronts_c.upload(fd, st);
+    d_a_src_c.upload(as, st);
+    d_a_dst_c.upload(ad, st);
+    d_a_colptr_c.upload(ac, st);
+    d_leaf_desc.upload(desc, st);
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    condensed_ok = true;
+    return true;
 }
 
 }  // namespace mgbhip

@@ -7,6 +7,7 @@
 #pragma once
 #include "common.hpp"
 #include "mf_analysis.hpp"
+#include "kernels.hpp"
 
 namespace mgbhip {
 
@@ -31,11 +32,23 @@ class MfSolver {
     MfPlan plan;
     // coords (optional): n x dim row-major locations of the unknowns, an ordering hint (mf_analysis.hpp)
     void analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st,
-                 const double* coords = nullptr, int dim = 0);
+                 const double* coords = nullptr, int dim = 0, bool protect_peeled = false);
     // factor the matrix whose CSR values (same pattern as analyze) live at d_values.
     // Asynchronous; the not-SPD flag is read back by status().
     // direct = true: d_values is the value space of set_direct_map (slab | shared | border) instead of the CSR array
-    void factor(const double* d_values, hipStream_t st, StageTimers* timers, bool direct = false);
+    // condensed = true (needs direct and enable_condensed): the leaf fronts are already in the arena, written by the
+    // element kernel of the same Newton iteration; the leaf level is skipped and no matrix entry is read
+    void factor(const double* d_values, hipStream_t st, StageTimers* timers, bool direct = false, bool condensed = false);
+    // Condensed leaves (kernels.hpp, launch_elem_f2_condense).  N elements of P nodes, ucol[e * P + i] = unknown of the
+    // u component at node i of element e or -1, node P - 1 interior to the element, slack unknown of broken node q =
+    // slack0 + q.  Checks that the plan's leaf level is exactly one front per element with the element's slacks and
+    // interior node as pivots; builds the leaf descriptors and the border-only scatter lists.  nnz / tail_base as in
+    // set_direct_map.  Returns false (and changes nothing) when the plan has another shape.
+    bool enable_condensed(int64_t N, int P, const int32_t* ucol, int64_t slack0, int64_t nnz, int64_t tail_base, hipStream_t st);
+    bool condensed_ready() const { return condensed_ok; }
+    const LeafDesc* leaf_desc() const { return d_leaf_desc.p; }
+    double* arena() { return d_arena.p; }
+    int32_t* leaf_status() { return d_status.p + 1; }
     // Second scatter list for the same plan: CSR position q -> value_map[q], border entry v -> tail_base + v.
     void set_direct_map(const int32_t* value_map, int64_t nnz, int64_t tail_base, hipStream_t st);
     bool has_direct_map() const { return d_a_src_direct.n > 0; }
@@ -51,7 +64,10 @@ class MfSolver {
     int status(hipStream_t st);     // synchronises; MGBHIP_OK or MGBHIP_ERR_NOT_SPD
     // enqueue the copy of the flag only (pinned destination); interpret it after the caller's sync
     void status_async(int32_t* h_dst, hipStream_t st) const;
-    static int status_from(int32_t flag) { return flag ? MGBHIP_ERR_NOT_SPD : MGBHIP_OK; }
+    static int status_from(const int32_t* flags2, bool with_leaves) {
+        return (flags2[0] || (with_leaves && flags2[1])) ? MGBHIP_ERR_NOT_SPD : MGBHIP_OK;
+    }
+    bool factored_condensed = false;     // the current factors took their leaves from a condensing f2
     bool analyzed = false;
     // The inverse-based large-front kernels apply W = L_jj^{-1} where a substitution would run: as fast as a
     // GEMM, but only forward stable in cond(L_jj).  `robust` (set by the Newton loop when a direction fails its
@@ -72,6 +88,16 @@ class MfSolver {
     DevBuf<int64_t> d_ug_ptr, d_ug_src;   // per large front: for every local index the children's update-vector entries, in child order
     DevBuf<double> d_arena, d_uvec, d_y, d_tbig, d_tsol, d_dscr, d_dvec;
     DevBuf<int32_t> d_status;
+    // condensed leaves
+    bool condensed_ok = false;
+    std::vector<FrontDev> h_fronts;
+    std::vector<int32_t> h_a_dst;         // a_dst as uploaded (packed-triangle remaps applied)
+    DevBuf<FrontDev> d_fronts_c;
+    DevBuf<int32_t> d_a_src_c, d_a_dst_c, d_a_colptr_c;
+    DevBuf<LeafDesc> d_leaf_desc;
+    const FrontDev* cur_fr = nullptr;     // arrays of the factorization in progress
+    const int32_t* cur_adst = nullptr;
+    const int32_t* cur_acol = nullptr;
     std::vector<std::vector<MfLaunch>> level_launches;   // per level, leaves first (factorization: one per LDS class)
     std::vector<std::vector<MfLaunch>> level_solves;     // triangular solves: all LDS-class fronts of a level in one launch
     int32_t lds_cap = 88;           // largest m factored out of LDS

@@ -721,11 +721,59 @@ void mgbhip_problem::eval_f01_launch(int level, const double* d_s, const double*
     cnt.f1++;
 }
 
-void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc, bool materialize) {
+bool mgbhip_problem::try_enable_condensed(int level) {
+    Level& L = levels[level];
+    static const bool off = [] { const char* e = getenv("MGBHIP_NO_CONDENSE"); return e && e[0] == '1'; }();
+    if (off || dense || !L.selection || !L.direct || nu != 2 || p != 7 || L.hRptr.empty()) return false;
+    if (!L.solver.analyzed || !L.solver.has_direct_map()) return false;
+    // R of a selection level: row (state, node) has at most one entry, equal to 1.  Slack unknowns must be numbered
+    // slack0 + node (R_fine = blockdiag(R_dirichlet, I), src/multigrid.jl:474-512).
+    const int64_t slack0 = L.m - n;
+    if (slack0 < 0 || L.rows != 2 * n) return false;
+    std::vector<int32_t> ucol((size_t)n, -1);
+    for (int64_t node = 0; node < n; ++node) {
+        const int32_t b = L.hRptr[node], e = L.hRptr[node + 1];
+        if (e - b > 1) return false;
+        if (e - b == 1) ucol[(size_t)node] = L.hRcol[b];
+        const int64_t rs = n + node;
+        if (L.hRptr[rs + 1] - L.hRptr[rs] != 1 || (int64_t)L.hRcol[L.hRptr[rs]] != slack0 + node) return false;
+    }
+    const bool ok = L.solver.enable_condensed(N, p, ucol.data(), slack0, L.nnz, hel_cap + L.nshared, stream());
+    if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
+        fprintf(stderr, "[mgbhip] level %d: condensed leaves %s\n", level, ok ? "enabled" : "not applicable");
+    return ok;
+}
+
+void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc, bool materialize,
+                             const double* rhs) {
     ensure_plan(level);
     hipStream_t st = stream();
     Level& L = levels[level];
     int E_ymask = 0;
+    if (L.condense && !materialize && rhs != nullptr && L.selection && L.direct && !dense) {
+        // Newton loop on a level with condensed leaves: one kernel evaluates the element blocks and eliminates the
+        // element-local unknowns; nothing else is assembled (the other fronts receive every contribution through the
+        // leaves' update blocks)
+        StageScope sc(ctx->timers, level + 1 == (int)levels.size() ? "f2" : "f2_coarse");
+        ElemParams E = base_params(level, d_s, d_zz, d_cc);
+        E.leaf_desc = L.solver.leaf_desc();
+        E.leaf_arena = L.solver.arena();
+        E.leaf_g = rhs;
+        E.leaf_slack0 = L.m - n;
+        E.leaf_status = L.solver.leaf_status();
+        MGB_HIP_CHECK(hipMemsetAsync(E.leaf_status, 0, sizeof(int32_t), st));
+        if (launch_elem_f2_condense(E, st)) {
+            L.have_H = true;
+            L.H_in_slab = true;
+            L.H_condensed = true;
+            L.condensed_rhs = rhs;
+            hel_level = level;
+            L.factored = false;
+            cnt.f2++;
+            return;
+        }
+    }
+    L.H_condensed = false;
     {
         // fine-level launches are timed apart: they are the ones the HBM roofline is quoted on
         StageScope sc(ctx->timers, level + 1 == (int)levels.size() ? "f2" : "f2_coarse");
@@ -801,7 +849,9 @@ void mgbhip_problem::factor(int level, const double* rhs) {
             for (int64_t j = 0; j < L.m; ++j)
                 for (int d = 0; d < xdim; ++d) cen[(size_t)j * xdim + d] = wsum[j] > 0 ? cen[(size_t)j * xdim + d] / wsum[j] : 0.0;
         }
-        L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st, cen.empty() ? nullptr : cen.data(), xdim);
+        // candidates for condensed leaves (try_enable_condensed) keep their per-element leaf fronts unmerged
+        const bool leaves = L.selection && L.direct && !dense && nu == 2 && p == 7;
+        L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st, cen.empty() ? nullptr : cen.data(), xdim, leaves);
         if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
             fprintf(stderr, "[mgbhip] symbolic analysis level %d (m=%lld, nnz=%lld): %.2f s\n", level, (long long)L.m,
                     (long long)L.nnz, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -814,9 +864,14 @@ void mgbhip_problem::factor(int level, const double* rhs) {
             L.solver.set_direct_map(L.h_vmap.data(), L.nnz, hel_cap + L.nshared, st);
             std::vector<int32_t>().swap(L.h_vmap);        // 4 B per nonzero: not needed again
         }
+        if (!L.condense_tried) {          // from the next f2 on the element kernel writes the leaf fronts itself
+            L.condense_tried = true;
+            L.condense = try_enable_condensed(level);
+        }
+        MGB_REQUIRE(!L.H_condensed || rhs == L.condensed_rhs, "condensed leaves were formed for another right-hand side");
         double* tail = d_hel.p + hel_cap + L.nshared;
         launch_border_tail(rhs, tail, L.m, st);
-        L.solver.factor(d_hel.p, st, &ctx->timers, true);
+        L.solver.factor(d_hel.p, st, &ctx->timers, true, L.H_condensed);
         L.border_state2 = 2;
         L.factored = true;
         cnt.factor++;

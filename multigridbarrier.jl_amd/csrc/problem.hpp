@@ -68,6 +68,9 @@ struct Level {
     DevBuf<int32_t> sh_q;                 // CSR positions of the shared entries
     std::vector<int32_t> h_vmap;          // CSR position -> index into [slab | shared | border]
     bool H_in_slab = false;               // the last eval_f2 of this level left H in d_hel (not in Hval)
+    bool condense_tried = false, condense = false;   // leaf fronts written by the element kernel (kernels.hpp)
+    bool H_condensed = false;             // the last eval_f2 did so: d_hel holds no blocks, the arena holds the leaves
+    const double* condensed_rhs = nullptr;
     int border_state2 = 0;                // 2: the current factors came from the slab path with a Newton right-hand side
     int border_state = 0;                 // tail of Hval: 0 unset, 1 identity border (solve), 2 Newton right-hand side (solve_border)
 };
@@ -123,7 +126,11 @@ struct mgbhip_problem {
     void eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
     // materialize = false (Newton loop): on direct levels only the shared entries are summed, H is not formed as a CSR
     // value array and the next factor(level, rhs) reads the slab (valid until the next eval_f2 of any level)
-    void eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc, bool materialize = true);
+    // rhs (with materialize = false): the gradient the following factor(level, rhs) will carry; on levels with
+    // condensed leaves (try_enable_condensed) the element kernel then writes the leaf fronts of the factorization itself
+    void eval_f2(int level, const double* d_s, const double* d_zz, const double* d_cc, bool materialize = true,
+                 const double* rhs = nullptr);
+    bool try_enable_condensed(int level);
     int64_t hel_cap = 0;                   // doubles of the element-block slab region of d_hel; extras live behind it
     int hel_level = -1;                    // level whose blocks + shared sums d_hel currently holds (direct mode), or -1
     // returns MGBHIP_OK or MGBHIP_ERR_NOT_SPD; x = H^{-1} g on the device

@@ -106,7 +106,7 @@ EXPORTS = [
     "mgbhip_create", "mgbhip_destroy", "mgbhip_last_error", "mgbhip_version", "mgbhip_problem_create",
     "mgbhip_problem_destroy", "mgbhip_problem_set_box", "mgbhip_problem_set_barrier_weights",
     "mgbhip_level_size", "mgbhip_f0", "mgbhip_f1", "mgbhip_f2", "mgbhip_hessian_pattern", "mgbhip_solve",
-    "mgbhip_set_hessian", "mgbhip_solve_newton",
+    "mgbhip_set_hessian", "mgbhip_solve_newton", "mgbhip_newton_direction",
     "mgbhip_node_barrier", "mgbhip_node_slack", "mgbhip_mgb_core", "mgbhip_matched_t",
     "mgbhip_default_options", "mgbhip_stage_ms", "mgbhip_reset_stage_timers", "mgbhip_solver_stats",
     "mgbhip_vec_alloc", "mgbhip_vec_free", "mgbhip_vec_len", "mgbhip_vec_upload", "mgbhip_vec_download",
@@ -150,6 +150,7 @@ def load_library():
     lib.mgbhip_solve.argtypes = [C.c_void_p, C.c_int32, _dp, _dp]
     lib.mgbhip_set_hessian.argtypes = [C.c_void_p, C.c_int32, _dp]
     lib.mgbhip_solve_newton.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp]
+    lib.mgbhip_newton_direction.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp, _ip]
     lib.mgbhip_node_barrier.argtypes = [C.c_void_p, _dp, _dp, _dp]
     lib.mgbhip_node_slack.argtypes = [C.c_void_p, _dp, _dp]
     lib.mgbhip_mgb_core.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(Options), C.POINTER(_CoreResult)]
@@ -495,6 +496,15 @@ class DeviceProblem:
         if check:
             _check(self.lib, status)
         return x, lam.value, status
+
+    def newton_direction(self, level: int, s, c, z0):
+        """(x, lambda^2, condensed): one Newton direction formed exactly as in the resident loop."""
+        s, c, z0 = _f64(s), np.asfortranarray(c, dtype=np.float64), _f64(z0)
+        x = np.empty(self.level_sizes[level])
+        lam, cond = C.c_double(), C.c_int32()
+        _check(self.lib, self.lib.mgbhip_newton_direction(self.handle, level, _ptr(s), _ptr(c), _ptr(z0), _ptr(x),
+                                                          C.cast(C.byref(lam), _dp), C.byref(cond)))
+        return x, lam.value, bool(cond.value)
 
     def node_barrier(self, z, want_Dz: bool = False):
         z = _f64(z)

@@ -5,7 +5,8 @@ import scipy.sparse as sp
 import mgb_amd as m
 
 CASES = [("fem2d_P2", 3, 1.5, {}), ("fem2d_P2", 5, 3.5, {}), ("fem2d_P2", 5, 1.0, dict(max_coarse=40)),
-         ("fem3d", 3, 1.5, {})]
+         ("fem3d", 3, 1.5, {}),
+         ("fem2d_P2", 7, 1.0, {})]       # large fronts: multi-workgroup path, LDS-sized fronts folded into it
 GRADES = (0, 6, 12)           # cond(H) ~ 10^grade x the diagonally dominant core's
 
 

@@ -55,3 +55,35 @@ def test_both_solve_paths_are_backward_stable_and_gated_kernels_agree(tmp_path):
         finally:
             D.close()
     print("worst componentwise backward error per kernel selection:", {k: (f"{v[0]:.2e}", v[1]) for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("L,p", [(3, 1.5), (5, 1.0), (6, 1.5)])
+def test_condensed_leaves_reproduce_the_assembled_newton_direction(L, p):
+    """Fine level of fem2d_P2: from the second evaluation on the element kernel eliminates every element's slack and
+    bubble unknowns itself and writes the leaf fronts of the factorization (no element block reaches HBM, no shared
+    entry is summed).  The Newton direction must be the one of the assembled system: against the generic path
+    (materialised H, forward + backward sweeps) and against SciPy on the device's own H."""
+    import mgb_amd as m
+    import scipy.sparse.linalg as spla
+    from helpers import stacked
+    from mgb_amd.device import DeviceMGBProblem
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), L)), p=p)
+    D = DeviceMGBProblem(prob)
+    try:
+        P = D.main
+        J = len(P.level_sizes) - 1
+        rng = np.random.default_rng(5)
+        z0, c = stacked(prob.g), 0.1 * prob.f
+        for trial in range(3):
+            s = 1e-3 * rng.standard_normal(P.level_sizes[J])
+            x, lam, condensed = P.newton_direction(J, s, c, z0)
+            assert condensed == (trial > 0)                       # the first call builds the plan and the leaf map
+            g = P.f1(J, s, c, z0)
+            H = P.f2(J, s, c, z0).tocsc()
+            x_ref = spla.spsolve(H, g)
+            assert np.linalg.norm(H @ x - g) <= 1e-10 * np.linalg.norm(g)
+            assert np.linalg.norm(x - x_ref) <= 1e-9 * np.linalg.norm(x_ref)
+            assert abs(lam - g @ x_ref) <= 1e-10 * abs(g @ x_ref)
+            assert np.linalg.norm(P.solve(J, g) - x) <= 1e-10 * np.linalg.norm(x)
+    finally:
+        D.close()
