@@ -526,41 +526,69 @@ __global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (active) {
+        {
+            // The finished leaf front: square column-major (entry (r, c) at r + c*m) straight to the arena, or -- packed
+            // leaves -- the lower triangle (column c at c*m - c(c-1)/2) staged in LDS and copied out in one coalesced
+            // run of m(m+1)/2 doubles per element.
             const int m = (int)(ld.packed & 15u);
-            double* Fg = Pm.leaf_arena + ld.F_off;
+            const bool pk = Pm.leaf_packed != 0;
             int pos[P];
 #pragma unroll
             for (int i = 0; i < P; ++i) pos[i] = (int)((ld.packed >> (4 + 4 * i)) & 15u);
-            const double d7 = Xs[1], bb = Xs[0];
-            const double inv7 = 1.0 / d7;
-            bad = bad || (j == PB && ((d7 == 0.0) || !isfinite(d7)));
-            // slack column j: pivot, zeros against the later slacks, the u rows, the border row
-            double* Cj = Fg + (size_t)j * m;
-            Cj[j] = ssj;
+            double d7 = 1.0, bb = 0.0, inv7 = 1.0, f = 0.0, xc[P];
 #pragma unroll
-            for (int rr = 0; rr < P; ++rr)
-                if (rr > j) Cj[rr] = 0.0;
-            Cj[P] = usc[PB] * inv;
+            for (int i = 0; i < P; ++i) xc[i] = 0.0;
+            if (active) {
+                d7 = Xs[1];
+                bb = Xs[0];
+                inv7 = 1.0 / d7;
 #pragma unroll
-            for (int i = 0; i < PB; ++i)
-                if (pos[i] != 15) Cj[pos[i]] = usc[i] * inv;
-            Cj[m - 1] = beta * inv;
-            if (j == PB) {                             // column of the interior node
-                double* Cb = Fg + (size_t)P * m;
-                Cb[P] = d7;
+                for (int i = 0; i < P; ++i) xc[i] = Xc[i];
+                f = (j < PB) ? xc[j] * inv7 : 0.0;
+                bad = bad || (j == PB && ((d7 == 0.0) || !isfinite(d7)));
+            }
+            double* Fg = Pm.leaf_arena + ld.F_off;
+            double* S = Fg;                               // destination of the scattered writes
+            if (pk) {
+                __syncthreads();                          // every lane has read its scratch: the staging area may overlap it
+                S = sh + (size_t)el * 120;
+            }
+            auto at = [&](int rr, int cc) -> int { return pk ? cc * m - (cc * (cc - 1)) / 2 + (rr - cc) : rr + cc * m; };
+            if (active) {
+                // slack column j: pivot, zeros against the later slacks, the u rows, the border row
+                S[at(j, j)] = ssj;
+#pragma unroll
+                for (int rr = 0; rr < P; ++rr)
+                    if (rr > j) S[at(rr, j)] = 0.0;
+                S[at(P, j)] = usc[PB] * inv;
 #pragma unroll
                 for (int i = 0; i < PB; ++i)
-                    if (pos[i] != 15) Cb[pos[i]] = Xc[i] * inv7;
-                Cb[m - 1] = bb * inv7;
-                Fg[(size_t)(m - 1) * m + (m - 1)] = corner - bb * bb * inv7;
-            } else if (pos[j] != 15) {                 // update column of element node j
-                const double f = Xc[j] * inv7;
-                double* Cu = Fg + (size_t)pos[j] * m;
+                    if (pos[i] != 15) S[at(pos[i], j)] = usc[i] * inv;
+                S[at(m - 1, j)] = beta * inv;
+                if (j == PB) {                             // column of the interior node
+                    S[at(P, P)] = d7;
 #pragma unroll
-                for (int i = 0; i < PB; ++i)
-                    if (pos[i] != 15 && pos[i] >= pos[j]) Cu[pos[i]] = up[i] - Xc[i] * f;
-                Cu[m - 1] = bj - bb * f;
+                    for (int i = 0; i < PB; ++i)
+                        if (pos[i] != 15) S[at(pos[i], P)] = xc[i] * inv7;
+                    S[at(m - 1, P)] = bb * inv7;
+                    S[at(m - 1, m - 1)] = corner - bb * bb * inv7;
+                } else if (pos[j] != 15) {                 // update column of element node j
+#pragma unroll
+                    for (int i = 0; i < PB; ++i)
+                        if (pos[i] != 15 && pos[i] >= pos[j]) S[at(pos[i], pos[j])] = up[i] - xc[i] * f;
+                    S[at(m - 1, pos[j])] = bj - bb * f;
+                }
+            }
+            if (pk) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (e < Pm.N) {
+                    const LeafDesc l2 = Pm.leaf_desc[e];       // lane G-1 of the group takes part in the copy
+                    const int mm = (int)(l2.packed & 15u);
+                    double* dstF = Pm.leaf_arena + l2.F_off;
+                    for (int t = r; t < mm * (mm + 1) / 2; t += G) dstF[t] = S[t];
+                }
             }
         }
         if (bad) atomicOr(Pm.leaf_status, 1);

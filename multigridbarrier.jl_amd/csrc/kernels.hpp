@@ -45,6 +45,7 @@ struct ElemParams {
     const double* leaf_g;                    // gradient in level coefficients (the border column is -g)
     int64_t leaf_slack0;                     // column of the slack unknown of broken node 0 (slack of node i = leaf_slack0 + i)
     int32_t* leaf_status;                    // |= 1 on a zero / non-finite pivot
+    int32_t leaf_packed;                     // leaf fronts are packed lower triangles (FrontDev::packed)
 };
 
 // Fine-level Newton systems: H of the default problem couples the p broken slack unknowns of an element (diagonal

@@ -78,6 +78,24 @@ __device__ __forceinline__ double fast_recip(double d) {
     return x;
 }
 
+// Entry (r, j), r >= j, of a child's update block.  Square children: U = offset of (k, k), M = the child's m (> 0).
+// Packed leaf children (FrontDev::packed): U = offset of (k, k) in the packed triangle, M = -(m - k).
+__device__ __forceinline__ int64_t child_entry(int64_t U, int32_t M, int j, int r) {
+    return M > 0 ? U + (int64_t)j * M + r : U + (int64_t)j * (-M) - (j * (j - 1)) / 2 + (r - j);
+}
+__device__ __forceinline__ void child_update_desc(const FrontDev& C, int64_t& U, int32_t& M) {
+    if (C.packed) {
+        U = C.F_off + (int64_t)C.k * C.m - (C.k * (C.k - 1)) / 2;
+        M = -(C.m - C.k);
+    } else {
+        U = C.F_off + (int64_t)C.k * C.m + C.k;
+        M = C.m;
+    }
+}
+__device__ __forceinline__ int64_t tiny_entry(const FrontDev& F, int r, int c) {        // (r, c), r >= c, of a leaf front
+    return F.packed ? (int64_t)c * F.m - (c * (c - 1)) / 2 + (r - c) : r + (int64_t)c * F.m;
+}
+
 // In-register LDL' of an nb x nb block: lane r holds row r of the lower triangle in a[0..r].
 // 32 x 31 / 2 shuffle + FMA pairs, no memory traffic; nb is wave-uniform.
 template <int NBT>
@@ -141,9 +159,8 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     int32_t pM = 0, pB = 0;
     if (tid < min(CHILD_CHUNK, F.nchild)) {
         const FrontDev C = fr[children[F.child_off + tid]];
-        pU = C.F_off + (int64_t)C.k * C.m + C.k;
+        child_update_desc(C, pU, pM);
         pR = C.rel_off;
-        pM = C.m;
         pB = C.m - C.k;
     }
     for (int i = tid; i < mm; i += nt) W[i] = 0.0;
@@ -171,9 +188,11 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                 cU[tid] = pU; cR[tid] = pR; cM[tid] = pM; cB[tid] = pB;
             } else {
                 const FrontDev C = fr[children[F.child_off + cbase + tid]];
-                cU[tid] = C.F_off + (int64_t)C.k * C.m + C.k;
+                int64_t u_; int32_t m_;
+                child_update_desc(C, u_, m_);
+                cU[tid] = u_;
                 cR[tid] = C.rel_off;
-                cM[tid] = C.m;
+                cM[tid] = m_;
                 cB[tid] = C.m - C.k;
             }
         }
@@ -203,7 +222,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                                 if (r >= j) {
                                     const int32_t* rl = rel + cR[c];
                                     dst[u] = rl[r] + co(rl[j]);
-                                    val[u] = arena[cU[c] + (int64_t)j * cM[c] + r];
+                                    val[u] = arena[child_entry(cU[c], cM[c], j, r)];
                                 }
                             }
                         }
@@ -239,7 +258,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                         if (r >= j) {
                             const int32_t* rl = rel + cR[c];
                             dst[u] = rl[r] + co(rl[j]);
-                            val[u] = arena[cU[c] + (int64_t)j * cM[c] + r];
+                            val[u] = arena[child_entry(cU[c], cM[c], j, r)];
                         }
                     }
                 }
@@ -254,11 +273,10 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                     const int32_t* rlg = rel + cR[c];
                     for (int j = tid; j < b; j += nt) crl[j] = rlg[j];
                     __syncthreads();
-                    const double* U = arena + cU[c];
                     const int mc = cM[c];
                     for (int j = ty; j < b; j += TYn) {
                         const int dcol = co(crl[j]);
-                        const double* Uc = U + (int64_t)j * mc;
+                        const double* Uc = arena + child_entry(cU[c], mc, j, 0);     // (r, j) at Uc[r]; packed children shift by j
                         for (int r = j + tx; r < b; r += 4 * TX) {      // four rows per lane in flight
                             const int r1 = r + TX, r2 = r + 2 * TX, r3 = r + 3 * TX;
                             const double u0 = Uc[r];
@@ -401,9 +419,8 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
     int32_t pM = 0, pB = 0;
     if (lane < min(64, F.nchild)) {
         const FrontDev C = fr[children[F.child_off + lane]];
-        pU = C.F_off + (int64_t)C.k * C.m + C.k;
+        child_update_desc(C, pU, pM);
         pR = C.rel_off;
-        pM = C.m;
         pB = C.m - C.k;
     }
     for (int i = lane; i < PK; i += 64) W[i] = 0.0;
@@ -418,9 +435,11 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
                 cU[lane] = pU; cR[lane] = pR; cM[lane] = pM; cB[lane] = pB;
             } else {
                 const FrontDev C = fr[children[F.child_off + cbase + lane]];
-                cU[lane] = C.F_off + (int64_t)C.k * C.m + C.k;
+                int64_t u_; int32_t m_;
+                child_update_desc(C, u_, m_);
+                cU[lane] = u_;
                 cR[lane] = C.rel_off;
-                cM[lane] = C.m;
+                cM[lane] = m_;
                 cB[lane] = C.m - C.k;
             }
         }
@@ -444,7 +463,7 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
                             if (r >= j) {
                                 const int32_t* rl = rel + cR[c];
                                 dst[u] = pidx(rl[r], rl[j]);
-                                val[u] = arena[cU[c] + (int64_t)j * cM[c] + r];
+                                val[u] = arena[child_entry(cU[c], cM[c], j, r)];
                             }
                         }
                     }
@@ -460,7 +479,6 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
                 for (int u = 0; u < ng; ++u) {
                     const int c = c0 + u, b = cB[c], mc = cM[c];
                     const int32_t* rl = rel + cR[c];
-                    const double* U = arena + cU[c];
                     for (int e = lane; e < b * b; e += 256) {       // four entries per lane in flight
                         int dd[4];
                         double vv[4];
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
                                 const int j = ee / b, r = ee - j * b;
                                 if (r >= j) {
                                     dd[q] = pidx(rl[r], rl[j]);
-                                    vv[q] = U[(int64_t)j * mc + r];
+                                    vv[q] = arena[child_entry(cU[c], mc, j, r)];
                                 }
                             }
                         }
@@ -1118,7 +1136,7 @@ __global__ __launch_bounds__(256) void mf_factor_tiny(const FrontDev* __restrict
         double* Fg = arena + F.F_off;
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-            if (c <= r) Fg[r + (int64_t)c * m] = a[c];
+            if (c <= r) Fg[tiny_entry(F, r, c)] = a[c];
     }
 }
 
@@ -1139,8 +1157,8 @@ __global__ __launch_bounds__(256) void mf_forward_tiny(const FrontDev* __restric
     double t = (row && r < k) ? b[myidx] : 0.0;
     double l[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) l[j] = (row && j < k && r > j) ? Fm[r + (int64_t)j * m] : 0.0;
-    const double dr = (row && r < k) ? Fm[r + (int64_t)r * m] : 1.0;
+    for (int j = 0; j < 16; ++j) l[j] = (row && j < k && r > j) ? Fm[tiny_entry(F, r, j)] : 0.0;
+    const double dr = (row && r < k) ? Fm[tiny_entry(F, r, r)] : 1.0;
     int kmax = k;
     kmax = max(kmax, __shfl_xor(kmax, 16, 64));
     kmax = max(kmax, __shfl_xor(kmax, 32, 64));
@@ -1172,7 +1190,7 @@ __global__ __launch_bounds__(256) void mf_backward_tiny(const FrontDev* __restri
     double t = row ? ((r < k) ? y[myidx] : x[myidx]) : 0.0;
     double l[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) l[j] = (row && j < k && r > j) ? Fm[r + (int64_t)j * m] : 0.0;
+    for (int j = 0; j < 16; ++j) l[j] = (row && j < k && r > j) ? Fm[tiny_entry(F, r, j)] : 0.0;
     int kmax = k;
     kmax = max(kmax, __shfl_xor(kmax, 16, 64));
     kmax = max(kmax, __shfl_xor(kmax, 32, 64));
@@ -2159,7 +2177,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     std::vector<FrontDev> fd(nf);
     for (int32_t i = 0; i < nf; ++i) {
         const Front& f = plan.fronts[i];
-        fd[i] = FrontDev{f.k, f.m, f.nchild, f.a_cnt, f.F_off, f.idx_off, f.u_off, f.child_off, f.rel_off, f.a_off, f.acol_off, -1};
+        fd[i] = FrontDev{f.k, f.m, f.nchild, f.a_cnt, f.F_off, f.idx_off, f.u_off, f.child_off, f.rel_off, f.a_off, f.acol_off, -1, 0, 0};
     }
     d_front_idx.upload(plan.front_idx, st);
     d_children.upload(plan.children, st);
@@ -2207,11 +2225,14 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
         }
     }
     static const int32_t classes[] = {16, 32, 48, 64, 88, 128};
-    // Optional size gates of the two fastest kernel families (A/B switches of tests/test_gpu_solver.py).  Round 2 kept
-    // both off systems of < 1024 unknowns after one creeping 37-unknown solve failed with them; round 3 found all
-    // kernel selections equally backward stable on graded matrices (2.9e-13 componentwise) and the 27-problem sweep,
-    // that case included (5356 vs 5355 iterations), in agreement with the oracle without gates: default 0 = no gate.
-    static const int64_t inv_min_n = [] { const char* e = getenv("MGBHIP_INV_MIN_N"); return e ? atoll(e) : 0ll; }();
+    // Size gates of the two fastest kernel families (A/B switches of tests/test_gpu_solver.py).  Round 2 kept both off
+    // systems of < 1024 unknowns after two creeping solves failed with them.  Round 3: all kernel selections are
+    // equally backward stable on graded matrices (2.9e-13 componentwise) and the 27-problem sweep agrees with the
+    // oracle without any gate (the 37-unknown case that motivated the wave gate: 5356 vs 5355 iterations), so the
+    // one-wave kernel is ungated.  The inverse-based large-front path keeps its gate: without it config 4's phase I
+    // (fem3d L=6, 9 000 iterations hugging the wall on a 145-unknown level) ends in "Initial centering failed" --
+    // applying W = L_jj^{-1} is only forward stable in cond(L_jj), and such systems gain nothing from it.
+    static const int64_t inv_min_n = [] { const char* e = getenv("MGBHIP_INV_MIN_N"); return e ? atoll(e) : 1024ll; }();
     static const bool merge_groups = [] { const char* e = getenv("MGBHIP_NO_MERGE_GROUPS"); return !(e && e[0] == '1'); }();
     static const int64_t wave_min_n = [] { const char* e = getenv("MGBHIP_WAVE_MIN_N"); return e ? atoll(e) : 0ll; }();
     uses_inv = false;
@@ -2307,6 +2328,27 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
             const Front& ch = plan.fronts[plan.children[f.child_off + c]];
             for (int32_t j = 0; j < ch.m - ch.k; ++j) ug_src[(size_t)fill[plan.rel[ch.rel_off + j]]++] = ch.u_off + j;
         }
+    }
+    {   // Leaf fronts (m <= 16, the 16-lanes-per-front kernels) as packed lower triangles: m(m+1)/2 contiguous doubles
+        // instead of m*m, read back by their parents' extend-add and by the sweeps.  Only when every parent is an LDS
+        // front (the large-front assembly kernels read square children).
+        static const bool no_pack = [] { const char* e = getenv("MGBHIP_NO_PACKED_LEAVES"); return e && e[0] == '1'; }();
+        bool ok = !no_pack;
+        for (auto& lev : level_launches)
+            for (auto& L : lev)
+                if (L.tiny)
+                    for (int32_t q = L.first; q < L.first + L.count && ok; ++q) {
+                        const int32_t par = plan.fronts[q].parent;
+                        ok = par < 0 || !on_big_path[par];
+                    }
+        leaf_packed = false;
+        if (ok)
+            for (auto& lev : level_launches)
+                for (auto& L : lev)
+                    if (L.tiny) {
+                        leaf_packed = true;
+                        for (int32_t q = L.first; q < L.first + L.count; ++q) fd[q].packed = 1;
+                    }
     }
     if (ug_ptr.empty()) ug_ptr.push_back(0);
     if (ug_src.empty()) ug_src.push_back(0);

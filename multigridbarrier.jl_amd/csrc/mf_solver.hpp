@@ -15,6 +15,8 @@ struct FrontDev {
     int32_t k, m, nchild, a_cnt;
     int64_t F_off, idx_off, u_off, child_off, rel_off, a_off, acol_off;
     int64_t ug_off;        // large fronts: offset of the update-vector gather list (m + 1 pointers), -1 otherwise
+    int32_t packed;        // leaf fronts (m <= 16) stored as a packed lower triangle: column c at c*m - c(c-1)/2, rows c..m-1
+    int32_t pad_;
 };
 
 struct MfLaunch {          // one kernel launch: a contiguous range of fronts of one size class
@@ -46,6 +48,7 @@ class MfSolver {
     // set_direct_map.  Returns false (and changes nothing) when the plan has another shape.
     bool enable_condensed(int64_t N, int P, const int32_t* ucol, int64_t slack0, int64_t nnz, int64_t tail_base, hipStream_t st);
     bool condensed_ready() const { return condensed_ok; }
+    bool leaves_packed() const { return leaf_packed; }
     const LeafDesc* leaf_desc() const { return d_leaf_desc.p; }
     double* arena() { return d_arena.p; }
     int32_t* leaf_status() { return d_status.p + 1; }
@@ -90,6 +93,7 @@ class MfSolver {
     DevBuf<int32_t> d_status;
     // condensed leaves
     bool condensed_ok = false;
+    bool leaf_packed = false;            // the m <= 16 leaf fronts are stored as packed triangles (FrontDev::packed)
     std::vector<FrontDev> h_fronts;
     std::vector<int32_t> h_a_dst;         // a_dst as uploaded (packed-triangle remaps applied)
     DevBuf<FrontDev> d_fronts_c;

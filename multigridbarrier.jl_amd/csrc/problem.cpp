@@ -761,6 +761,7 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
         E.leaf_g = rhs;
         E.leaf_slack0 = L.m - n;
         E.leaf_status = L.solver.leaf_status();
+        E.leaf_packed = L.solver.leaves_packed() ? 1 : 0;
         MGB_HIP_CHECK(hipMemsetAsync(E.leaf_status, 0, sizeof(int32_t), st));
         if (launch_elem_f2_condense(E, st)) {
             L.have_H = true;

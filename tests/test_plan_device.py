@@ -35,9 +35,24 @@ def test_direct_values_equal_materialised_hessian_bitwise():
     single-contribution entries from the element-block slab and a small kernel sums the shared ones
     (problem.cpp: eval_f2(materialize=false), MfSolver::set_direct_map).  Same numbers, same order: complete solves
     must be bitwise those of the materialised path (MGBHIP_NO_DIRECT=1), iteration counts included."""
-    direct = _run({"MGBHIP_NO_DIRECT": "0"}, "solve")
+    direct = _run({"MGBHIP_NO_DIRECT": "0", "MGBHIP_NO_CONDENSE": "1"}, "solve")
     mat = _run({"MGBHIP_NO_DIRECT": "1"}, "solve")
     keys = [k for k in direct if k.startswith("solve/")]
     assert len(keys) == 2
     for k in keys:
         assert direct[k] == mat[k], k
+
+
+@pytest.mark.gpu
+def test_condensed_leaves_solve_equals_assembled_solve():
+    """Round 3: on the fine level of fem2d_P2 the element kernel eliminates each element's slack and bubble unknowns
+    itself (kernels.hpp: launch_elem_f2_condense), so the summation order of the leaf fronts differs from the assembled
+    path (MGBHIP_NO_CONDENSE=1): same Newton iteration counts, z equal to rounding."""
+    import numpy as np
+    cond = _run({}, "solve")
+    plain = _run({"MGBHIP_NO_CONDENSE": "1"}, "solve")
+    for name in ("fem2d_L4_p15", "fem1d_L5_p1"):
+        assert cond[f"solve/{name}"][1] == plain[f"solve/{name}"][1], name          # iteration counts
+        a, b = np.array(cond[f"z/{name}"]), np.array(plain[f"z/{name}"])
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), name
+    assert cond["solve/fem1d_L5_p1"][0] == plain["solve/fem1d_L5_p1"][0]              # fem1d has no condensed leaves: bitwise

@@ -46,6 +46,7 @@ def main():
             sol = m.mgb_solve(make())
             h = hashlib.sha256(np.ascontiguousarray(sol.z, dtype=np.float64).tobytes()).hexdigest()
             out[f"solve/{name}"] = [h, [int(v) for v in np.asarray(sol.SOL_main["its"]).ravel()]]
+            out[f"z/{name}"] = [float(v) for v in np.asarray(sol.z).ravel()]
     print(json.dumps(out))
 
 
