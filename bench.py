@@ -37,15 +37,12 @@ F2_MOVED_BYTES_PER_NODE = 248.0
 
 
 # Hierarchy policy.  The workload runs the reference default `amg(geom)` = amg_ruge_stuben(max_coarse=2)
-# (src/multigrid.jl:296).  With this package's restatement of AlgebraicMultigrid.jl's Ruge-Stueben that
-# ladder converges for p = 1.0 at L = 9; for p = 1.5 the initial centring stalls in the 2-4-unknown
-# coarse spaces at L >= 8 (device and oracle agree, tests/test_gpu_parity.py::
-# test_default_hierarchy_initial_centring_at_L8_is_pinned), so the p = 1.5 line uses
-# the smallest deviation that converges, max_coarse=10 -- a documented knob of the reference's factory
+# (src/multigrid.jl:296) whenever it converges: p = 1.0 at L = 9 does, and since round 3 (compensated sums in the
+# coarse assembly) p = 1.5 does at L <= 8.  At L = 9, p = 1.5 the initial centring still ends in
+# the 2-unknown space with lambda^2 <= 0 (device and oracle, tests/dev/logs/); the p = 1.5 line then falls back to the
+# smallest deviation that converges, max_coarse=10 -- a documented knob of the reference's factory
 # (src/multigrid.jl:304-306) -- and says so in its `hierarchy` field.
 def hierarchies(p, L):
-    if p >= 1.25 and L >= 8:
-        return [dict(max_coarse=10), dict(max_coarse=50), dict(max_coarse=300)]
     return [dict(), dict(max_coarse=10), dict(max_coarse=300)]
 
 
@@ -201,6 +198,9 @@ def main():
 
     prob, D, used, setup = run_workload(m, DeviceMGBProblem, mgb_driver, MGBConvergenceFailure, args.L, args.p, dev_index,
                                         args.warmup, rank)
+    if traffic is not None and used != hierarchies(args.p, args.L)[0]:
+        # the PMC child passes profiled the first hierarchy variant; the timed workload fell through to another one
+        traffic, traffic_note = None, f"PMC passes ran on hierarchy {hierarchies(args.p, args.L)[0]}, the workload on {used}: not comparable"
     barrier()
     t0 = time.perf_counter()
     its_total, solve_s, core_s, last = timed_solves(mgb_driver, D, args.steps)

@@ -711,6 +711,31 @@ __global__ __launch_bounds__(256) void elem_f01_fast(const ElemParams Pm) {
     if (tid == 0) Pm.out_partial[blockIdx.x] = sh[0];
 }
 
+// ---- compensated sums --------------------------------------------------------------------------
+// The coarse-level sums run over every element of the mesh, and near the end of a barrier solve one node's term can
+// exceed the rest by sixteen orders of magnitude (an iterate 1e-13 from the cone's wall: Hessian entries ~ 1e16, soft
+// eigenvalues ~ 1e1).  A plain running sum then loses the other 10^5 terms below the ulp of the large one -- an
+// absolute error of hundreds in a matrix whose smallest eigenvalue is 34: H comes out indefinite by summation
+// noise alone (tests/dev/logs/gpu_coarse_noise_probe_L8_p1.5.txt).  TwoSum accumulation (Knuth) carries the rounding
+// error of every addition in a second word: the sum is the correctly rounded one to a few ulps, whatever the order.
+struct DSum {
+    double s = 0.0, c = 0.0;
+    __device__ __forceinline__ void add(double x) {
+        const double t = s + x;
+        const double bp = t - s;
+        c += (s - (t - bp)) + (x - bp);
+        s = t;
+    }
+    __device__ __forceinline__ void merge(double s2, double c2) { add(s2); c += c2; }
+    __device__ __forceinline__ double value() const { return s + c; }
+};
+__device__ __forceinline__ void dsum_wave_reduce(DSum& a) {      // fixed shuffle tree over the 64 lanes; result in lane 0
+    for (int off = 32; off > 0; off >>= 1) {
+        const double s2 = __shfl_down(a.s, off, 64), c2 = __shfl_down(a.c, off, 64);
+        a.merge(s2, c2);
+    }
+}
+
 // ---- reductions ------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t count,
@@ -827,10 +852,10 @@ __global__ __launch_bounds__(256) void csr_matvec_wave_kernel(int64_t rows, cons
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= rows) return;
-    double s = 0.0;
-    for (int32_t q = ptr[i] + lane; q < ptr[i + 1]; q += 64) s += val[q] * x[col[q]];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) y[i] = ADD ? y[i] + s : s;
+    DSum a;
+    for (int32_t q = ptr[i] + lane; q < ptr[i + 1]; q += 64) a.add(val[q] * x[col[q]]);
+    dsum_wave_reduce(a);
+    if (lane == 0) y[i] = ADD ? y[i] + a.value() : a.value();
 }
 
 // Very long rows (restriction onto a handful of coarse unknowns: every row of R' spans a large
@@ -846,24 +871,34 @@ __global__ __launch_bounds__(256) void csr_matvec_chunk_kernel(const int32_t* __
     const int row = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
     const int32_t q0 = ptr[row] + ch * CHUNK;
     const int32_t q1 = min(ptr[row + 1], q0 + CHUNK);
-    double s = 0.0;
-    for (int32_t q = q0 + tid; q < q1; q += 256) s += val[q] * x[col[q]];
-    red[tid] = s;
+    __shared__ double redc[256];
+    DSum a;
+    for (int32_t q = q0 + tid; q < q1; q += 256) a.add(val[q] * x[col[q]]);
+    red[tid] = a.s;
+    redc[tid] = a.c;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) red[tid] += red[tid + off];
+        if (tid < off) {
+            DSum b;
+            b.s = red[tid]; b.c = redc[tid];
+            b.merge(red[tid + off], redc[tid + off]);
+            red[tid] = b.s; redc[tid] = b.c;
+        }
         __syncthreads();
     }
-    if (tid == 0) partial[(int64_t)row * nchunk + ch] = red[0];
+    if (tid == 0) {            // (sum, carried error) of the chunk
+        partial[2 * ((int64_t)row * nchunk + ch)] = red[0];
+        partial[2 * ((int64_t)row * nchunk + ch) + 1] = redc[0];
+    }
 }
 
 __global__ __launch_bounds__(256) void csr_matvec_chunk_sum_kernel(int64_t rows, const double* __restrict__ partial,
                                                                    int nchunk, double* __restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows) return;
-    double s = 0.0;
-    for (int c = 0; c < nchunk; ++c) s += partial[i * nchunk + c];
-    y[i] = s;
+    DSum a;
+    for (int c = 0; c < nchunk; ++c) a.merge(partial[2 * (i * nchunk + c)], partial[2 * (i * nchunk + c) + 1]);
+    y[i] = a.value();
 }
 
 // zfull = z0 + R*s  (src/convex.jl:156): one thread per broken row, so the element kernels
@@ -937,9 +972,16 @@ __global__ __launch_bounds__(256) void gather_assemble_kernel(int64_t nnz, const
                                                               double* __restrict__ Hval) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= nnz) return;
-    double s = 0.0;
-    for (int32_t t = cptr[q]; t < cptr[q + 1]; ++t) s += slab[cidx[t]];
-    Hval[q] = s;
+    const int32_t beg = cptr[q], end = cptr[q + 1];
+    if (end - beg <= 4) {              // a handful of element contributions: nothing to compensate
+        double s = 0.0;
+        for (int32_t t = beg; t < end; ++t) s += slab[cidx[t]];
+        Hval[q] = s;
+        return;
+    }
+    DSum a;
+    for (int32_t t = beg; t < end; ++t) a.add(slab[cidx[t]]);
+    Hval[q] = a.value();
 }
 
 // Direct-value levels: only the structural nonzeros shared between elements are summed (into a compact array
@@ -971,10 +1013,10 @@ __global__ __launch_bounds__(256) void gather_assemble_wave_kernel(int64_t nnz, 
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nnz) return;
-    double s = 0.0;
-    for (int32_t t = cptr[q] + lane; t < cptr[q + 1]; t += 64) s += slab[cidx[t]];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) Hval[q] = s;
+    DSum a;
+    for (int32_t t = cptr[q] + lane; t < cptr[q + 1]; t += 64) a.add(slab[cidx[t]]);
+    dsum_wave_reduce(a);
+    if (lane == 0) Hval[q] = a.value();
 }
 
 // Very long lists (the coarsest levels: a handful of nonzeros, each summing every element): one wave per
@@ -991,17 +1033,17 @@ __global__ __launch_bounds__(256) void gather_assemble_chunk_kernel(int64_t nnz,
     const int64_t q = w / nchunk;
     const int32_t c = (int32_t)(w - q * nchunk);
     const int32_t beg = cptr[q] + c * ch, end = min(cptr[q + 1], beg + ch);
-    double s = 0.0;
+    DSum a;
     for (int32_t t = beg + lane; t < end; t += 256) {      // four loads in flight per lane
         const int32_t t1 = t + 64, t2 = t + 128, t3 = t + 192;
         const double a0 = slab[cidx[t]];
         const double a1 = t1 < end ? slab[cidx[t1]] : 0.0;
         const double a2 = t2 < end ? slab[cidx[t2]] : 0.0;
         const double a3 = t3 < end ? slab[cidx[t3]] : 0.0;
-        s += a0; s += a1; s += a2; s += a3;
+        a.add(a0); a.add(a1); a.add(a2); a.add(a3);
     }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) part[w] = s;
+    dsum_wave_reduce(a);
+    if (lane == 0) { part[2 * w] = a.s; part[2 * w + 1] = a.c; }
 }
 
 __global__ __launch_bounds__(256) void gather_assemble_chunk_reduce(int64_t nnz, int32_t nchunk, const double* __restrict__ part,
@@ -1009,10 +1051,10 @@ __global__ __launch_bounds__(256) void gather_assemble_chunk_reduce(int64_t nnz,
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nnz) return;
-    double s = 0.0;
-    for (int32_t c = lane; c < nchunk; c += 64) s += part[q * nchunk + c];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) Hval[q] = s;
+    DSum a;
+    for (int32_t c = lane; c < nchunk; c += 64) a.merge(part[2 * (q * nchunk + c)], part[2 * (q * nchunk + c) + 1]);
+    dsum_wave_reduce(a);
+    if (lane == 0) Hval[q] = a.value();
 }
 
 // General (coarse) levels: one wave per element computes the projected block

@@ -227,7 +227,7 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     {
         size_t tch = 1;
         for (auto& L : P->levels) tch = std::max(tch, (size_t)L.T_chunks * (size_t)L.m);
-        P->d_tchunk.alloc(tch);
+        P->d_tchunk.alloc(2 * tch);            // (sum, carried error) per chunk
     }
     P->d_flag.alloc(4);
     MGB_HIP_CHECK(hipStreamSynchronize(st));
@@ -577,7 +577,7 @@ void mgbhip_problem::ensure_plan(int level) {
         if (hc[L.nnz] / L.nnz > 2048) {
             L.gather_chunk = (int32_t)std::max<int64_t>(1024, (maxlen + 63) / 64);
             L.gather_nchunk = (int32_t)((maxlen + L.gather_chunk - 1) / L.gather_chunk);
-            L.gather_part.alloc((size_t)L.nnz * (size_t)L.gather_nchunk);
+            L.gather_part.alloc(2 * (size_t)L.nnz * (size_t)L.gather_nchunk);      // (sum, carried error) per chunk
         }
     }
     if (!selection) {

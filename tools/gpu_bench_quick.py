@@ -18,4 +18,13 @@ for st in ("f0", "f1", "f01", "f2", "assemble", "f0_coarse", "f1_coarse", "f01_c
     ms, cnt = D.main.stage_ms(st)
     if cnt:
         print(f"  {st:16s} n={cnt:5d} avg {1e3*ms/cnt:8.1f} us  total {ms:8.1f} ms")
+if os.environ.get("MGBHIP_LEVEL_TIMING") == "1":
+    for pre in ("fac", "bwd"):
+        row = []
+        for lv in range(40):
+            ms, cnt = D.main.stage_ms(f"{pre}_lv{lv:02d}")
+            if cnt == 0:
+                break
+            row.append(f"{ms:.1f}/{cnt}")
+        print(pre, "total ms / launches per tree level:", " ".join(row))
 D.close()
