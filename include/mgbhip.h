@@ -191,6 +191,23 @@ int mgbhip_set_hessian(mgbhip_problem* prob, int32_t level, const double* values
  * [H -g; -g' -1] is factored, so the forward substitution rides along the factorization, and one backward
  * sweep returns x = H^{-1} g; lambda2 (optional) = <g, x>.                                                  */
 int mgbhip_solve_newton(mgbhip_problem* prob, int32_t level, const double* g, double* x, double* lambda2);
+/* ---- one process per GPU: domain decomposition of the resident loop ----
+ * The problem handed to mgbhip_problem_create is then this rank's SLICE: its elements, and per level the columns of
+ * R restricted to the unknowns its elements touch plus the interface unknowns (those whose support meets more than
+ * one rank), both in an order common to all ranks.  Per level: the interface columns (local indices, ascending) and
+ * an ownership mask (1 where this rank counts an unknown in dot products and norms, 0 elsewhere; interface unknowns
+ * are owned by exactly one rank).  The library then keeps s distributed with a replicated interface: f0 and the
+ * scalars of the Newton loop are summed over ranks, f1 sums its interface entries, every rank eliminates its
+ * interior unknowns and the assembled interface front of the factorization is summed over ranks before each rank
+ * factors it.  `allreduce` sums (op 0) or maximises (op 1) `count` doubles in place over all ranks and returns 0;
+ * the buffer is host memory unless accepts_device_ptr was set, in which case large buffers are passed as device
+ * pointers that are ready on the handle's stream when the call is made (the callee must complete before it returns).
+ * Must be set before the first evaluation; mgbhip_mgb_core then runs the same control flow on every rank.       */
+typedef int (*mgbhip_allreduce_fn)(void* user, double* buf, int64_t count, int32_t op, int32_t on_device);
+int mgbhip_problem_set_sharding(mgbhip_problem* prob, int32_t level, int64_t n_iface,
+                                const int32_t* iface_cols, const double* own_mask /* m_J */);
+int mgbhip_problem_set_collective(mgbhip_problem* prob, mgbhip_allreduce_fn allreduce, void* user,
+                                  int32_t accepts_device_ptr);
 /* One Newton direction exactly as the resident loop forms it at (s, c, z0): g = f1, H = f2 left in the
  * element-block slab (fine levels: leaf fronts condensed inside the element kernel from the second call on),
  * bordered factorization, backward sweep.  x = H^{-1} g, lambda2 = <g, x>; *condensed (optional) reports

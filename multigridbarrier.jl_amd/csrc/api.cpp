@@ -256,6 +256,34 @@ int mgbhip_solve_newton(mgbhip_problem* P, int32_t level, const double* g, doubl
     MGB_API_END
 }
 
+int mgbhip_problem_set_sharding(mgbhip_problem* P, int32_t level, int64_t n_iface, const int32_t* iface_cols, const double* own_mask) {
+    MGB_API_BEGIN_ON(P)
+    check_level(P, level);
+    mgbhip::Level& L = P->levels[level];
+    MGB_REQUIRE(!L.solver.analyzed, "sharding must be set before the first solve of the level");
+    MGB_REQUIRE(own_mask != nullptr && n_iface >= 0 && n_iface <= L.m && (n_iface == 0 || iface_cols), "bad sharding arguments");
+    L.h_iface.assign(iface_cols, iface_cols + n_iface);
+    for (int64_t i = 0; i < n_iface; ++i) {
+        MGB_REQUIRE(L.h_iface[i] >= 0 && L.h_iface[i] < L.m, "interface column out of range");
+        MGB_REQUIRE(i == 0 || L.h_iface[i] > L.h_iface[i - 1], "interface columns must be strictly increasing");
+    }
+    L.d_iface.upload(L.h_iface, P->stream());
+    L.own.upload(own_mask, (size_t)L.m, P->stream());
+    MGB_HIP_CHECK(hipStreamSynchronize(P->stream()));
+    L.sharded = true;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_problem_set_collective(mgbhip_problem* P, mgbhip_allreduce_fn fn, void* user, int32_t accepts_device_ptr) {
+    MGB_API_BEGIN_ON(P)
+    P->coll_fn = fn;
+    P->coll_user = user;
+    P->coll_device = accepts_device_ptr != 0;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
 int mgbhip_newton_direction(mgbhip_problem* P, int32_t level, const double* s, const double* c, const double* z0, double* x,
                             double* lambda2, int32_t* condensed) {
     MGB_API_BEGIN_ON(P)

@@ -48,19 +48,23 @@ struct NewtonResult {
 
 struct VecStats { double sumsq, bad; };
 
-VecStats vec_stats(mgbhip_problem* P, const double* d_v, int64_t len) {
+// One process per GPU (include/mgbhip.h, mgbhip_problem_set_collective): vectors live on this rank's unknowns with the
+// interface replicated, so every reduction runs over the entries the rank owns (mask) and is then summed over ranks.
+VecStats vec_stats(mgbhip_problem* P, int level, const double* d_v, int64_t len) {
     hipStream_t st = P->stream();
-    launch_vec_stats(d_v, len, P->d_scratch.p, P->d_scal.p + 2, st);
+    launch_vec_stats(d_v, len, P->d_scratch.p, P->d_scal.p + 2, st, P->own_mask(level));
     MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (P->sharded()) P->allreduce_host(P->pin.d + 2, 2, 0);
     return VecStats{P->pin.d[2], P->pin.d[3]};
 }
 
-double dev_dot(mgbhip_problem* P, const double* a, const double* b, int64_t len) {
+double dev_dot(mgbhip_problem* P, int level, const double* a, const double* b, int64_t len) {
     hipStream_t st = P->stream();
-    launch_dot(a, b, len, P->d_scratch.p, P->d_scal.p + 4, st);
+    launch_dot(a, b, len, P->d_scratch.p, P->d_scal.p + 4, st, P->own_mask(level));
     MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 4, P->d_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
     MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (P->sharded()) P->allreduce_host(P->pin.d + 4, 1, 0);
     return P->pin.d[4];
 }
 
@@ -71,10 +75,12 @@ struct NewtonCtx {
     const double* d_c;
     int64_t m;
     double F0(const double* d_s) { return P->eval_f0(level, d_s, d_zJ, d_c); }
-    void F1(const double* d_s, double* d_out) { P->eval_f1(level, d_s, d_zJ, d_c, d_out); }
+    // d_part: where a sharded problem keeps this rank's partial sums of the gradient (the right-hand side of its local elimination)
+    void F1(const double* d_s, double* d_out, double* d_part) { P->eval_f1(level, d_s, d_zJ, d_c, d_out, P->sharded() ? d_part : nullptr); }
+    const double* rhs_of_g() const { return P->sharded() ? P->d_gpart.p : P->d_g.p; }
     // H stays in the slab where the level allows; g (the right-hand side of the solve that follows) lets the fine level
     // condense the element-local unknowns inside the element kernel
-    void F2(const double* d_s) { P->eval_f2(level, d_s, d_zJ, d_c, false, P->d_g.p); }
+    void F2(const double* d_s) { P->eval_f2(level, d_s, d_zJ, d_c, false, rhs_of_g()); }
 };
 
 // One line-search trial shared by both searches: evaluates F0/F1 at xn (already formed in
@@ -85,11 +91,16 @@ struct NewtonCtx {
 bool trial_values(NewtonCtx& C, double& ynext, double& gnorm_next, int32_t* moved = nullptr) {
     mgbhip_problem* P = C.P;
     hipStream_t st = P->stream();
-    P->eval_f01_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c, P->d_gn.p);
-    launch_vec_stats(P->d_gn.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st);
+    P->eval_f01_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c, P->d_gn.p, P->sharded() ? P->d_gnpart.p : nullptr);
+    launch_vec_stats(P->d_gn.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st, P->own_mask(C.level));
     MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d, P->d_scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     MGB_HIP_CHECK(hipMemcpyAsync(P->pin.i, P->d_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (P->sharded()) {              // value, |g|^2, non-finite count and the "moved" flag in one sum over ranks
+        P->pin.d[1] = (double)P->pin.i[0];
+        P->allreduce_host(P->pin.d, 4, 0);
+        P->pin.i[0] = P->pin.d[1] != 0.0 ? 1 : 0;
+    }
     if (moved) *moved = P->pin.i[0];
     ynext = P->pin.d[0];
     if (!std::isfinite(ynext)) return false;
@@ -136,8 +147,8 @@ bool linesearch_illinois(NewtonCtx& C, const mgbhip_options& opt, double inc, do
         P->touch();
         const double f = C.F0(P->d_xn.p);
         if (!std::isfinite(f)) throw Reject();
-        C.F1(P->d_xn.p, P->d_gn.p);
-        const double v = dev_dot(P, P->d_gn.p, P->d_nv.p, C.m);
+        C.F1(P->d_xn.p, P->d_gn.p, P->d_gnpart.p);
+        const double v = dev_dot(P, C.level, P->d_gn.p, P->d_nv.p, C.m);
         if (!std::isfinite(v)) throw Reject();
         return v;
     };
@@ -182,8 +193,9 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
     double y = C.F0(P->d_x.p);
     if (!std::isfinite(y)) throw InvalidArgument("newton: initial objective value is not finite");
     double ymin = y;
-    C.F1(P->d_x.p, P->d_g.p);
-    VecStats gs = vec_stats(P, P->d_g.p, C.m);
+    if (P->sharded()) { P->d_gpart.ensure((size_t)C.m); P->d_gnpart.ensure((size_t)C.m); }
+    C.F1(P->d_x.p, P->d_g.p, P->d_gpart.p);
+    VecStats gs = vec_stats(P, C.level, P->d_g.p, C.m);
     if (gs.bad != 0.0 || !std::isfinite(gs.sumsq)) throw InvalidArgument("newton: initial gradient has non-finite entries");
     double gnorm = std::sqrt(gs.sumsq);
     double gmin = gnorm;
@@ -201,14 +213,19 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         auto t0 = std::chrono::steady_clock::now();
         int fstatus = MGBHIP_OK;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            P->factor(C.level, P->d_g.p);                   // the gradient rides along: no forward sweep afterwards
+            P->factor(C.level, C.rhs_of_g());               // the gradient rides along: no forward sweep afterwards
             P->trisolve_carried(C.level, P->d_nv.p);
             // pivot flag, direction statistics and lambda^2 = <g, n> in one round trip
-            launch_dir_stats(P->d_nv.p, P->d_g.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st);
+            launch_dir_stats(P->d_nv.p, P->d_g.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st, P->own_mask(C.level));
             MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
             L.solver.status_async(P->pin.i + 1, st);
             MGB_HIP_CHECK(hipStreamSynchronize(st));
             fstatus = MfSolver::status_from(P->pin.i + 1, L.solver.factored_condensed);
+            if (P->sharded()) {          // every rank must take the same branch: the pivot flag travels with the sums
+                P->pin.d[5] = fstatus != MGBHIP_OK ? 1.0 : 0.0;
+                P->allreduce_host(P->pin.d + 2, 4, 0);
+                fstatus = P->pin.d[5] != 0.0 ? MGBHIP_ERR_NOT_SPD : MGBHIP_OK;
+            }
             // The fast large-front kernels apply inverted 32 x 32 diagonal blocks; near the edge of singularity
             // that loses digits a substitution keeps.  A failed pivot, a non-finite direction or lambda^2 <= 0
             // is re-done once with the substitution kernels before the reference's own tests see it.
@@ -248,6 +265,7 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         if (moved) {
             std::swap(P->d_x, P->d_xn);
             std::swap(P->d_g, P->d_gn);
+            std::swap(P->d_gpart, P->d_gnpart);
         }
         y = ynext;
         gnorm = gnorm_next;
@@ -321,6 +339,7 @@ double c_dot_Dz(mgbhip_problem* P, const double* d_c) {
     double v;
     P->d_scal.download(&v, 1, st);
     MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (P->sharded()) P->allreduce_host(&v, 1, 0);
     return v;
 }
 
@@ -333,6 +352,7 @@ bool slack_feasible(mgbhip_problem* P, std::vector<double>& hbuf) {
     MGB_HIP_CHECK(hipStreamSynchronize(st));
     double mx = -INFINITY;
     for (double v : hbuf) mx = std::fmax(mx, v);
+    if (P->sharded()) P->allreduce_host(&mx, 1, 1);
     return mx < 0;
 }
 
@@ -460,16 +480,37 @@ int matched_t_run(mgbhip_problem* P, const double* z, const double* c, double t_
     P->touch();
     *t_out = t_default;
     // gphi = f1(c = 0); gc = f1(c) - gphi; H = f2
-    P->eval_f1(lev, P->d_x.p, P->d_z0.p, P->d_c.p, P->d_g.p);          // gphi -> d_g
-    P->eval_f1(lev, P->d_x.p, P->d_z0.p, P->d_c0.p, P->d_gn.p);         // f1(c) -> d_gn
+    const bool sh = P->sharded();
+    if (sh) { P->d_gpart.ensure((size_t)m); P->d_gnpart.ensure((size_t)m); }
+    P->eval_f1(lev, P->d_x.p, P->d_z0.p, P->d_c.p, P->d_g.p, sh ? P->d_gpart.p : nullptr);      // gphi -> d_g
+    P->eval_f1(lev, P->d_x.p, P->d_z0.p, P->d_c0.p, P->d_gn.p, sh ? P->d_gnpart.p : nullptr);   // f1(c) -> d_gn
     launch_axpy(-1.0, P->d_g.p, P->d_gn.p, m, st);                      // gc -> d_gn
+    if (sh) launch_axpy(-1.0, P->d_gpart.p, P->d_gnpart.p, m, st);
     P->eval_f2(lev, P->d_x.p, P->d_z0.p, P->d_c0.p);
-    P->factor(lev);
-    if (P->levels[lev].solver.status(st) != MGBHIP_OK) return MGBHIP_OK;   // degenerate: keep t_default
-    P->trisolve(lev, P->d_g.p, P->d_nv.p);                              // nphi
-    P->trisolve(lev, P->d_gn.p, P->d_xn.p);                             // nc
-    const double d = dev_dot(P, P->d_gn.p, P->d_xn.p, m);
-    const double b = dev_dot(P, P->d_g.p, P->d_xn.p, m) + dev_dot(P, P->d_gn.p, P->d_nv.p, m);
+    if (sh) {
+        // domain decomposition: only the bordered factorization crosses ranks (the interface front carries the
+        // right-hand side), so each of the two solves is a factorization with its own border
+        P->d_tmp.ensure((size_t)m + 1);
+        P->factor(lev, P->d_gpart.p);
+        P->trisolve_carried(lev, P->d_tmp.p);
+        int bad = P->levels[lev].solver.status(st) != MGBHIP_OK;
+        MGB_HIP_CHECK(hipMemcpyAsync(P->d_nv.p, P->d_tmp.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, st));
+        P->levels[lev].factored = false;
+        P->factor(lev, P->d_gnpart.p);
+        P->trisolve_carried(lev, P->d_tmp.p);
+        bad |= P->levels[lev].solver.status(st) != MGBHIP_OK;
+        MGB_HIP_CHECK(hipMemcpyAsync(P->d_xn.p, P->d_tmp.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, st));
+        double fb = bad ? 1.0 : 0.0;
+        P->allreduce_host(&fb, 1, 0);
+        if (fb != 0.0) return MGBHIP_OK;
+    } else {
+        P->factor(lev);
+        if (P->levels[lev].solver.status(st) != MGBHIP_OK) return MGBHIP_OK;   // degenerate: keep t_default
+        P->trisolve(lev, P->d_g.p, P->d_nv.p);                              // nphi
+        P->trisolve(lev, P->d_gn.p, P->d_xn.p);                             // nc
+    }
+    const double d = dev_dot(P, lev, P->d_gn.p, P->d_xn.p, m);
+    const double b = dev_dot(P, lev, P->d_g.p, P->d_xn.p, m) + dev_dot(P, lev, P->d_gn.p, P->d_nv.p, m);
     if (!(d > 0)) return MGBHIP_OK;
     const double tstar = -b / (2 * d);
     if (!(std::isfinite(tstar) && tstar > 0)) return MGBHIP_OK;

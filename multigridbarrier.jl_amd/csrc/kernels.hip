@@ -756,16 +756,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
 // MODE 0: sum a*b ; MODE 1: sum a*a and count of non-finite a
 template <int MODE>
 __global__ __launch_bounds__(256) void block_reduce_kernel(const double* __restrict__ a, const double* __restrict__ b,
-                                                           int64_t n, double* __restrict__ partials) {
+                                                           int64_t n, double* __restrict__ partials,
+                                                           const double* __restrict__ mask) {
     __shared__ double red[256];
     __shared__ double red2[256];
     const int tid = threadIdx.x;
     double s = 0.0, bad = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
         const double v = a[i];
-        if (MODE == 0) s += v * b[i];
+        const double w = mask ? mask[i] : 1.0;       // domain decomposition: 1 on the entries this rank owns, else 0
+        if (MODE == 0) s += mask ? w * (v * b[i]) : v * b[i];
         else {
-            s += v * v;
+            s += mask ? w * (v * v) : v * v;
             bad += isfinite(v) ? 0.0 : 1.0;
         }
     }
@@ -785,15 +787,16 @@ __global__ __launch_bounds__(256) void block_reduce_kernel(const double* __restr
 // Newton direction statistics in one pass: sum v*v, count of non-finite v, and g.v (the same per-block partial sums
 // and trees as block_reduce_kernel<1> and <0>: identical values, two launches fewer per Newton iteration)
 __global__ __launch_bounds__(256) void dir_stats_kernel(const double* __restrict__ v, const double* __restrict__ g, int64_t n,
-                                                        double* __restrict__ partials) {
+                                                        double* __restrict__ partials, const double* __restrict__ mask) {
     __shared__ double red[3][256];
     const int tid = threadIdx.x;
     double s = 0.0, bad = 0.0, d = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
         const double x = v[i];
-        s += x * x;
+        const double w = mask ? mask[i] : 1.0;
+        s += mask ? w * (x * x) : x * x;
         bad += isfinite(x) ? 0.0 : 1.0;
-        d += g[i] * x;
+        d += mask ? w * (g[i] * x) : g[i] * x;
     }
     red[0][tid] = s; red[1][tid] = bad; red[2][tid] = d;
     __syncthreads();
@@ -1514,23 +1517,45 @@ static int reduce_blocks(int64_t n) {
 
 int64_t reduce_scratch_doubles(int64_t n) { return 3 * (int64_t)reduce_blocks(n); }
 
-void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st) {
+__global__ __launch_bounds__(256) void index_gather_kernel(const double* __restrict__ v, const int32_t* __restrict__ idx,
+                                                           int64_t cnt, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < cnt) out[i] = v[idx[i]];
+}
+__global__ __launch_bounds__(256) void index_scatter_kernel(const double* __restrict__ in, const int32_t* __restrict__ idx,
+                                                            int64_t cnt, double* __restrict__ v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < cnt) v[idx[i]] = in[i];
+}
+void launch_index_gather(const double* v, const int32_t* idx, int64_t cnt, double* out, hipStream_t st) {
+    if (cnt == 0) return;
+    hipLaunchKernelGGL(index_gather_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, v, idx, cnt, out);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+void launch_index_scatter(const double* in, const int32_t* idx, int64_t cnt, double* v, hipStream_t st) {
+    if (cnt == 0) return;
+    hipLaunchKernelGGL(index_scatter_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, in, idx, cnt, v);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st, const double* mask) {
     const int nb = reduce_blocks(n);
-    hipLaunchKernelGGL(block_reduce_kernel<1>, dim3(nb), dim3(256), 0, st, v, (const double*)nullptr, n, scratch);
+    hipLaunchKernelGGL(block_reduce_kernel<1>, dim3(nb), dim3(256), 0, st, v, (const double*)nullptr, n, scratch, mask);
     hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats, 2);
     MGB_HIP_CHECK(hipGetLastError());
 }
 
-void launch_dir_stats(const double* v, const double* g, int64_t n, double* scratch, double* stats3, hipStream_t st) {
+void launch_dir_stats(const double* v, const double* g, int64_t n, double* scratch, double* stats3, hipStream_t st,
+                      const double* mask) {
     const int nb = reduce_blocks(n);
-    hipLaunchKernelGGL(dir_stats_kernel, dim3(nb), dim3(256), 0, st, v, g, n, scratch);
+    hipLaunchKernelGGL(dir_stats_kernel, dim3(nb), dim3(256), 0, st, v, g, n, scratch, mask);
     hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats3, 3);
     MGB_HIP_CHECK(hipGetLastError());
 }
 
-void launch_dot(const double* a, const double* b, int64_t n, double* scratch, double* out, hipStream_t st) {
+void launch_dot(const double* a, const double* b, int64_t n, double* scratch, double* out, hipStream_t st, const double* mask) {
     const int nb = reduce_blocks(n);
-    hipLaunchKernelGGL(block_reduce_kernel<0>, dim3(nb), dim3(256), 0, st, a, b, n, scratch);
+    hipLaunchKernelGGL(block_reduce_kernel<0>, dim3(nb), dim3(256), 0, st, a, b, n, scratch, mask);
     hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, out, 1);
     MGB_HIP_CHECK(hipGetLastError());
 }

@@ -297,6 +297,11 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
     b.coords = coords;
     b.dim = dim;
 
+    for (int64_t t = 0; t < opt.ntop; ++t) {            // interface unknowns: invisible to peeling and dissection
+        const int32_t v = opt.top[t];
+        if (v < 0 || v >= n || b.removed[v]) throw std::runtime_error("mf_analyze: bad interface list");
+        b.removed[v] = 1;
+    }
     b.peel(plan);
     // supernodes [0, nsn_peeled) are the element-local unknowns (round 1: the broken slacks, round 2: the element-
     // interior nodes they expose); later rounds peel ordinary mesh nodes
@@ -306,6 +311,11 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
         for (int32_t v = 0; v < n; ++v)
             if (!b.removed[v]) rest.push_back(v);
         b.dissect(rest);
+    }
+    int32_t top_sn = -1;
+    if (opt.ntop > 0) {                                 // ... and eliminated last, as one supernode
+        top_sn = (int32_t)b.sn_piv.size();
+        b.new_supernode(opt.top, (size_t)opt.ntop);
     }
     const int32_t nsn = (int32_t)b.sn_piv.size();
     const std::vector<int32_t>& pos = b.pos;
@@ -353,6 +363,7 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
             const bool relaxed = opt.merge_max_m > 0 && merged_m <= opt.merge_max_m;
             if (!exact && !relaxed) continue;
             if (opt.protect_peeled && s < nsn_peeled && f >= nsn_peeled) continue;
+            if (f == top_sn || s == top_sn) continue;       // the interface front stays exactly the interface
             // an exact fit costs no flops, but merging a large child serialises two pivot chains that
             // the tree would run side by side (the half-domain separator into the root separator):
             // only fronts that stay within one LDS workgroup are amalgamated
@@ -453,6 +464,7 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
         std::sort(ch.begin(), ch.end());
         plan.children.insert(plan.children.end(), ch.begin(), ch.end());
     }
+    if (top_sn >= 0) plan.iface_front = newid[top_sn];
     plan.level_ptr.assign(maxlevel + 2, 0);
     for (int32_t i = 0; i < nf; ++i) plan.level_ptr[plan.fronts[i].level + 1]++;
     for (int32_t l = 0; l <= maxlevel; ++l) plan.level_ptr[l + 1] += plan.level_ptr[l];

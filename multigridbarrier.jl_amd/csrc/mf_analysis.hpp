@@ -55,6 +55,7 @@ struct MfPlan {
     // statistics
     int64_t peeled = 0;
     int32_t peel_rounds = 0;
+    int32_t iface_front = -1;           // MfOptions::top: the front holding the interface unknowns
 };
 
 struct MfOptions {
@@ -75,6 +76,12 @@ struct MfOptions {
     // across that line): on fine levels the peeled fronts are then exactly the per-element static-condensation leaves
     // the condensing element kernel writes (MfSolver::enable_condensed).
     bool protect_peeled = false;
+    // Domain decomposition (one process per GPU): `top` lists the interface unknowns of this
+    // rank's local system, in an order common to all ranks.  They are kept out of peeling and dissection and form ONE
+    // final front (k = |top|, boundary = the border), never amalgamated with anything: its assembled frontal matrix is
+    // the rank's contribution to the interface Schur complement, summed over ranks before it is factored.
+    const int32_t* top = nullptr;
+    int64_t ntop = 0;
 };
 
 // Symmetric pattern in CSR (both triangles present, diagonal optional).  Values are not

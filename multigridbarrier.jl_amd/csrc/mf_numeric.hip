@@ -2163,9 +2163,11 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __res
 }  // namespace
 
 void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st,
-                       const double* coords, int dim, bool protect_peeled) {
+                       const double* coords, int dim, bool protect_peeled, const int32_t* top, int64_t ntop) {
     MfOptions opt;
     opt.protect_peeled = protect_peeled;
+    opt.top = top;
+    opt.ntop = ntop;
     // tuning overrides (defaults are the measured best on MI355X)
     if (const char* e = getenv("MGBHIP_LEAF")) opt.leaf_size = atoi(e);
     if (const char* e = getenv("MGBHIP_SEPW")) opt.sep_weight = atof(e);
@@ -2297,6 +2299,39 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
                 const bool next_lds = G[g + 1].cls != 0;
                 if (next_lds && !G[g].tiny && (G[g].count < 256 || 4 * (int64_t)G[g].count < G[g + 1].count)) absorb(g + 1, g);
                 else ++g;
+            }
+        }
+    }
+    if (plan.iface_front >= 0) {
+        // the interface front gets a launch of its own on the large-front path (assemble / reduce / factor are separate
+        // kernels there, whatever its size)
+        const int32_t q = plan.iface_front;
+        for (auto& G : level_launches) {
+            for (size_t g = 0; g < G.size(); ++g) {
+                MfLaunch& L = G[g];
+                if (q < L.first || q >= L.first + L.count) continue;
+                auto part = [&](int32_t first, int32_t count) {
+                    MfLaunch P = L;
+                    P.first = first; P.count = count;
+                    P.max_m = 0; P.max_k = 0; P.max_child = 0;
+                    for (int32_t t = first; t < first + count; ++t) {
+                        P.max_m = std::max(P.max_m, plan.fronts[t].m);
+                        P.max_k = std::max(P.max_k, plan.fronts[t].k);
+                        P.max_child = std::max(P.max_child, plan.fronts[t].nchild);
+                    }
+                    return P;
+                };
+                std::vector<MfLaunch> out;
+                if (q > L.first) out.push_back(part(L.first, q - L.first));
+                MfLaunch I = part(q, 1);
+                I.cls = 0; I.tiny = false; I.wave = false; I.iface = true;
+                I.inv = (I.max_m <= BIG_INV_MAX_M && inv_ok && plan.n >= inv_min_n);
+                uses_inv = uses_inv || I.inv;
+                out.push_back(I);
+                if (q + 1 < L.first + L.count) out.push_back(part(q + 1, L.first + L.count - q - 1));
+                G.erase(G.begin() + (long)g);
+                G.insert(G.begin() + (long)g, out.begin(), out.end());
+                break;
             }
         }
     }
@@ -2518,6 +2553,32 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 else if (nbt <= 16) { if (packed) MGB_LAUNCH_SMALL(16, true); else MGB_LAUNCH_SMALL(16, false); }
                 else { if (packed) MGB_LAUNCH_SMALL(32, true); else MGB_LAUNCH_SMALL(32, false); }
 #undef MGB_LAUNCH_SMALL
+            } else if (L.iface) {
+                // assemble this rank's contribution, sum over ranks, then factor the complete front (every rank the same)
+                MGB_REQUIRE((bool)iface_reduce, "MfSolver: interface front without a reduction hook");
+                const Front& fi = plan.fronts[L.first];
+                const dim3 ga((L.max_m + CT - 1) / CT, 1);
+                launch_big_assemble(L, ga, d_values, a_src_p, st, false);
+                iface_reduce(d_arena.p + fi.F_off, (int64_t)fi.m * fi.m);
+                if (L.inv && !robust) {
+                    hipLaunchKernelGGL(mf_big_diag0, dim3(1), dim3(256), 0, st, cur_fr, L.first, d_arena.p, d_dscr.p, d_status.p);
+                    for (int j0 = 0; j0 < L.max_k; j0 += NB) {
+                        const int rem = L.max_m - j0;
+                        const int T = std::max(0, (rem - 1 + ST - 1) / ST);
+                        hipLaunchKernelGGL(mf_big_step, dim3(T * (T + 1) / 2 + 1, 1), dim3(256), 0, st, cur_fr, L.first, j0, d_arena.p,
+                                           d_dscr.p, d_dvec.p, d_status.p, 0);
+                    }
+                } else {
+                    for (int j0 = 0; j0 < L.max_k; j0 += NB) {
+                        const int rem = L.max_m - j0;
+                        hipLaunchKernelGGL(mf_big_panel, dim3(std::max(1, (rem - 1 + TR - 1) / TR), 1), dim3(256), 0, st, cur_fr,
+                                           L.first, j0, d_arena.p, d_dscr.p, d_status.p, j0 == 0 ? 1 : 0);
+                        const int T = (rem - 1 + ST - 1) / ST;
+                        if (T > 0)
+                            hipLaunchKernelGGL(mf_big_update, dim3(T * (T + 1) / 2 + 1, 1), dim3(256), 0, st, cur_fr, L.first, j0,
+                                               d_arena.p, d_dscr.p, d_status.p);
+                    }
+                }
             } else if (L.inv && !robust) {
                 const dim3 ga((L.max_m + CT - 1) / CT, L.count);
                 // block 0 of every front is factored by an extra workgroup of the gather launch when that kernel applies;

@@ -5,6 +5,8 @@
 // analyze() once per sparsity pattern (host, cached by the level), factor() + solve()
 // per Newton iteration on the device, all on the caller's stream.
 #pragma once
+#include <functional>
+
 #include "common.hpp"
 #include "mf_analysis.hpp"
 #include "kernels.hpp"
@@ -27,6 +29,8 @@ struct MfLaunch {          // one kernel launch: a contiguous range of fronts of
     bool tiny = false;     // leaf fronts with m <= 16: 16-lanes-per-front kernels
     bool wave = false;     // m <= 48 and only small children: one wave per front (mf_factor_wave), packed LDS triangle
     bool inv = false;      // large fronts on the inverse-based path (W_j = L_jj^{-1} in the arena, pivots in dvec)
+    bool iface = false;    // the interface front of a domain-decomposed system, alone in its launch: assembled, summed
+                           // over ranks (MfSolver::iface_reduce), then factored redundantly on every rank
 };
 
 class MfSolver {
@@ -34,7 +38,11 @@ class MfSolver {
     MfPlan plan;
     // coords (optional): n x dim row-major locations of the unknowns, an ordering hint (mf_analysis.hpp)
     void analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, hipStream_t st,
-                 const double* coords = nullptr, int dim = 0, bool protect_peeled = false);
+                 const double* coords = nullptr, int dim = 0, bool protect_peeled = false,
+                 const int32_t* top = nullptr, int64_t ntop = 0);
+    // Domain decomposition: called by factor() with the assembled interface front (device pointer, m*m doubles,
+    // column-major, lower triangle meaningful) -- the caller sums it over ranks in place on the solver's stream.
+    std::function<void(double*, int64_t)> iface_reduce;
     // factor the matrix whose CSR values (same pattern as analyze) live at d_values.
     // Asynchronous; the not-SPD flag is read back by status().
     // direct = true: d_values is the value space of set_direct_map (slab | shared | border) instead of the CSR array

@@ -675,10 +675,45 @@ double mgbhip_problem::eval_f0(int level, const double* d_s, const double* d_zz,
     eval_f0_launch(level, d_s, d_zz, d_cc);
     MGB_HIP_CHECK(hipMemcpyAsync(pin.d, d_scal.p, sizeof(double), hipMemcpyDeviceToHost, st));
     MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (sharded()) allreduce_host(pin.d, 1, 0);
     return pin.d[0];
 }
 
-void mgbhip_problem::eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout) {
+void mgbhip_problem::allreduce_host(double* h, int64_t count, int op) {
+    MGB_REQUIRE(coll_fn != nullptr, "no collective installed");
+    if (coll_fn(coll_user, h, count, op, 0) != 0) throw mgbhip::InvalidArgument("the caller's allreduce failed");
+}
+
+void mgbhip_problem::allreduce_device(double* d, int64_t count, int op) {
+    MGB_REQUIRE(coll_fn != nullptr, "no collective installed");
+    hipStream_t st = stream();
+    if (coll_device) {
+        MGB_HIP_CHECK(hipStreamSynchronize(st));            // the buffer is final before the callee's stream touches it
+        if (coll_fn(coll_user, d, count, op, 1) != 0) throw mgbhip::InvalidArgument("the caller's allreduce failed");
+        return;
+    }
+    coll_host.resize((size_t)count);
+    MGB_HIP_CHECK(hipMemcpyAsync(coll_host.data(), d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    allreduce_host(coll_host.data(), count, op);
+    MGB_HIP_CHECK(hipMemcpyAsync(d, coll_host.data(), sizeof(double) * (size_t)count, hipMemcpyHostToDevice, st));
+    MGB_HIP_CHECK(hipStreamSynchronize(st));               // coll_host may be reused by the next call
+}
+
+void mgbhip_problem::reduce_interface(int level, double* d_g, double* d_part) {
+    Level& L = levels[level];
+    if (!L.sharded) return;
+    hipStream_t st = stream();
+    if (d_part) MGB_HIP_CHECK(hipMemcpyAsync(d_part, d_g, sizeof(double) * (size_t)L.m, hipMemcpyDeviceToDevice, st));
+    const int64_t ni = (int64_t)L.h_iface.size();
+    if (ni == 0) return;
+    L.iface_buf.ensure((size_t)ni);
+    launch_index_gather(d_g, L.d_iface.p, ni, L.iface_buf.p, st);
+    allreduce_device(L.iface_buf.p, ni, 0);
+    launch_index_scatter(L.iface_buf.p, L.d_iface.p, ni, d_g, st);
+}
+
+void mgbhip_problem::eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout, double* d_part) {
     hipStream_t st = stream();
     const Level& L = levels[level];
     {
@@ -693,13 +728,15 @@ void mgbhip_problem::eval_f1(int level, const double* d_s, const double* d_zz, c
         else
             launch_csr_matvec(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, false, L.T_long, st);
     }
+    if (L.sharded) reduce_interface(level, d_gout, d_part);
     cnt.f1++;
 }
 
-void mgbhip_problem::eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout) {
+void mgbhip_problem::eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout,
+                                     double* d_part) {
     if (dense) {                    // the dense (spectral) path keeps its separate GEMV pipelines
         eval_f0_launch(level, d_s, d_zz, d_cc);
-        eval_f1(level, d_s, d_zz, d_cc, d_gout);
+        eval_f1(level, d_s, d_zz, d_cc, d_gout, d_part);
         return;
     }
     hipStream_t st = stream();
@@ -717,6 +754,7 @@ void mgbhip_problem::eval_f01_launch(int level, const double* d_s, const double*
         else
             launch_csr_matvec(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, false, L.T_long, st);
     }
+    if (L.sharded) reduce_interface(level, d_gout, d_part);
     cnt.f0++;
     cnt.f1++;
 }
@@ -852,7 +890,12 @@ void mgbhip_problem::factor(int level, const double* rhs) {
         }
         // candidates for condensed leaves (try_enable_condensed) keep their per-element leaf fronts unmerged
         const bool leaves = L.selection && L.direct && !dense && nu == 2 && p == 7;
-        L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st, cen.empty() ? nullptr : cen.data(), xdim, leaves);
+        if (L.sharded) {
+            mgbhip_problem* self = this;
+            L.solver.iface_reduce = [self](double* d, int64_t cnt2) { self->allreduce_device(d, cnt2, 0); };
+        }
+        L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st, cen.empty() ? nullptr : cen.data(), xdim, leaves,
+                         L.sharded ? L.h_iface.data() : nullptr, L.sharded ? (int64_t)L.h_iface.size() : 0);
         if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
             fprintf(stderr, "[mgbhip] symbolic analysis level %d (m=%lld, nnz=%lld): %.2f s\n", level, (long long)L.m,
                     (long long)L.nnz, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());

@@ -68,6 +68,11 @@ struct Level {
     DevBuf<int32_t> sh_q;                 // CSR positions of the shared entries
     std::vector<int32_t> h_vmap;          // CSR position -> index into [slab | shared | border]
     bool H_in_slab = false;               // the last eval_f2 of this level left H in d_hel (not in Hval)
+    // domain decomposition (mgbhip_problem_set_sharding): interface columns and the ownership mask of this rank
+    bool sharded = false;
+    std::vector<int32_t> h_iface;
+    DevBuf<int32_t> d_iface;
+    DevBuf<double> own, iface_buf;
     bool condense_tried = false, condense = false;   // leaf fronts written by the element kernel (kernels.hpp)
     bool H_condensed = false;             // the last eval_f2 did so: d_hel holds no blocks, the arena holds the leaves
     const double* condensed_rhs = nullptr;
@@ -113,6 +118,18 @@ struct mgbhip_problem {
     mutable const double* zf_s = nullptr;
     mutable const double* zf_z = nullptr;
     void touch() { ++zstamp; }
+    // one process per GPU (include/mgbhip.h: mgbhip_problem_set_collective)
+    mgbhip_allreduce_fn coll_fn = nullptr;
+    void* coll_user = nullptr;
+    bool coll_device = false;
+    bool sharded() const { return coll_fn != nullptr; }
+    std::vector<double> coll_host;
+    void allreduce_host(double* h, int64_t count, int op);          // in place
+    void allreduce_device(double* d, int64_t count, int op);        // in place, ordered on the handle's stream
+    // g (m_J entries, this rank's partial sums) -> interface entries summed over ranks; d_part (optional) keeps the partial
+    void reduce_interface(int level, double* d_g, double* d_part);
+    const double* own_mask(int level) const { return levels[level].sharded ? levels[level].own.p : nullptr; }
+    mgbhip::DevBuf<double> d_gpart, d_gnpart;                        // partial gradients (right-hand sides of the local eliminations)
 
     mgbhip::ElemParams base_params(int level, const double* d_s, const double* d_zz, const double* d_cc) const;
     hipStream_t stream() const { return ctx->stream; }
@@ -121,9 +138,10 @@ struct mgbhip_problem {
     double eval_f0(int level, const double* d_s, const double* d_zz, const double* d_cc);
     // kernels only: the value lands in d_scal[0]; the caller batches the read-back
     void eval_f0_launch(int level, const double* d_s, const double* d_zz, const double* d_cc);
-    void eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
+    // d_part (sharded problems): receives this rank's partial gradient before the interface entries are summed
+    void eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout, double* d_part = nullptr);
     // one line-search trial: f0 (value in d_scal[0]) and f1 (gradient in d_gout) from one sweep over the elements
-    void eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout);
+    void eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout, double* d_part = nullptr);
     // materialize = false (Newton loop): on direct levels only the shared entries are summed, H is not formed as a CSR
     // value array and the next factor(level, rhs) reads the slab (valid until the next eval_f2 of any level)
     // rhs (with materialize = false): the gradient the following factor(level, rhs) will carry; on levels with

@@ -92,6 +92,7 @@ class Options(C.Structure):
 
 STOP_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p)
 EARLY_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_double, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
 
 
 class _CoreResult(C.Structure):
@@ -106,7 +107,8 @@ EXPORTS = [
     "mgbhip_create", "mgbhip_destroy", "mgbhip_last_error", "mgbhip_version", "mgbhip_problem_create",
     "mgbhip_problem_destroy", "mgbhip_problem_set_box", "mgbhip_problem_set_barrier_weights",
     "mgbhip_level_size", "mgbhip_f0", "mgbhip_f1", "mgbhip_f2", "mgbhip_hessian_pattern", "mgbhip_solve",
-    "mgbhip_set_hessian", "mgbhip_solve_newton", "mgbhip_newton_direction",
+    "mgbhip_set_hessian", "mgbhip_solve_newton", "mgbhip_newton_direction", "mgbhip_problem_set_sharding",
+    "mgbhip_problem_set_collective",
     "mgbhip_node_barrier", "mgbhip_node_slack", "mgbhip_mgb_core", "mgbhip_matched_t",
     "mgbhip_default_options", "mgbhip_stage_ms", "mgbhip_reset_stage_timers", "mgbhip_solver_stats",
     "mgbhip_vec_alloc", "mgbhip_vec_free", "mgbhip_vec_len", "mgbhip_vec_upload", "mgbhip_vec_download",
@@ -151,6 +153,8 @@ def load_library():
     lib.mgbhip_set_hessian.argtypes = [C.c_void_p, C.c_int32, _dp]
     lib.mgbhip_solve_newton.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp]
     lib.mgbhip_newton_direction.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp, _ip]
+    lib.mgbhip_problem_set_sharding.argtypes = [C.c_void_p, C.c_int32, C.c_int64, _ip, _dp]
+    lib.mgbhip_problem_set_collective.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.mgbhip_node_barrier.argtypes = [C.c_void_p, _dp, _dp, _dp]
     lib.mgbhip_node_slack.argtypes = [C.c_void_p, _dp, _dp]
     lib.mgbhip_mgb_core.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(Options), C.POINTER(_CoreResult)]
@@ -519,6 +523,17 @@ class DeviceProblem:
         _check(self.lib, self.lib.mgbhip_node_slack(self.handle, _ptr(z), _ptr(out)))
         return out
 
+    def set_sharding(self, shards, collective, accepts_device_ptr: bool = False):
+        """One process per GPU (include/mgbhip.h): per level the interface columns + ownership mask of this rank's slice,
+        and the all-reduce the library calls (`collective`: an ALLREDUCE_FN thunk, kept alive by this object)."""
+        for level, sh in enumerate(shards):
+            ic = np.ascontiguousarray(sh.iface, dtype=np.int32)
+            own = _f64(sh.own)
+            _check(self.lib, self.lib.mgbhip_problem_set_sharding(self.handle, level, ic.size, ic.ctypes.data_as(_ip), _ptr(own)))
+        self._collective = collective
+        _check(self.lib, self.lib.mgbhip_problem_set_collective(self.handle, C.cast(collective, C.c_void_p), None,
+                                                               1 if accepts_device_ptr else 0))
+
     def set_box(self, b: float, R: float):
         _check(self.lib, self.lib.mgbhip_problem_set_box(self.handle, float(b), float(R)))
 
@@ -608,12 +623,16 @@ class DeviceMGBProblem:
     The feasibility image is created lazily (most starts are feasible) and shares the
     operator arrays of the main image."""
 
-    def __init__(self, prob: MGBProblem, device_id: int = 0, stream: Optional[int] = None):
+    def __init__(self, prob: MGBProblem, device_id: int = 0, stream: Optional[int] = None, shards=None, collective=None,
+                 accepts_device_ptr: bool = False):
         self.prob = prob
         self.ctx = HipContext(device_id, stream)
         self.M1 = dense_as_block(prob.M[0])
         self.main = DeviceProblem(self.ctx, self.M1, prob.Q)
         self._feas = None
+        self._shards, self._collective, self._coll_dev = shards, collective, accepts_device_ptr
+        if shards is not None:           # this process holds one rank's slice of a domain-decomposed problem (sharded.py)
+            self.main.set_sharding(shards[0], collective, accepts_device_ptr)
 
     @property
     def feasibility(self) -> DeviceProblem:
@@ -621,6 +640,8 @@ class DeviceMGBProblem:
             M2 = dense_as_block(self.prob.M[1])
             self._feas = DeviceProblem(self.ctx, M2, self.prob.Q, feasibility=True, NC=self.main.nD + 1,
                                        share=self.main)
+            if self._shards is not None:
+                self._feas.set_sharding(self._shards[1], self._collective, self._coll_dev)
         return self._feas
 
     def close(self):

@@ -243,3 +243,163 @@ class DeviceLocalEvaluator:
     def close(self):
         self.P.close()
         self.ctx.close()
+
+
+# =====================================================================================================================
+# Domain-decomposed Newton solve: one process per GPU (round 3)
+# =====================================================================================================================
+# Every rank keeps its contiguous element range and, per level J, the unknowns its elements touch (its interior I_r)
+# plus ALL interface unknowns Gamma_J (those whose support meets more than one rank), in ascending global order.  The
+# level-J coefficient vectors live on that local index set: interior entries exist on one rank, interface entries are
+# replicated bit for bit.  Per Newton iteration the library (csrc/driver.cpp, problem.cpp, mf_numeric.hip) exchanges
+#   * one small all-reduce of scalars per evaluation (f0, <g, n>, |g|^2, flags),
+#   * |Gamma_J| doubles per gradient (the interface entries of R' v),
+#   * the assembled interface front of the factorization, (|Gamma_J| + 1)^2 doubles: each rank eliminates its interior
+#     unknowns (its subtree of the elimination tree), the Schur complements are summed, and every rank factors the
+#     interface front redundantly -- the same numbers on every rank, so the replicated entries stay identical.
+# The fine iterate z is never exchanged: each rank updates the rows of its own elements.
+
+
+@dataclass
+class LevelShard:
+    cols: np.ndarray          # global column (unknown) ids of this rank's local unknowns, ascending
+    iface: np.ndarray         # local positions of the interface unknowns, ascending
+    own: np.ndarray           # 1.0 where this rank counts the unknown in dot products (interior: its one holder; interface: rank 0)
+
+
+def _rank_of_rows(R: sp.csr_matrix, n: int, p: int, parts) -> np.ndarray:
+    ends = np.array([p * e1 for (_, e1) in parts])
+    return np.searchsorted(ends, np.arange(R.shape[0]) % n, side="right")
+
+
+def shard_level(R, n: int, p: int, parts, rank: int) -> LevelShard:
+    R = sp.csr_matrix(R)
+    world = len(parts)
+    rows, cols = R.nonzero()
+    owner = _rank_of_rows(R, n, p, parts)[rows]
+    touch = sp.csr_matrix((np.ones(rows.size), (cols, owner)), shape=(R.shape[1], world))
+    touch.sum_duplicates()
+    nt = touch.getnnz(axis=1)
+    iface_glob = np.flatnonzero(nt > 1)
+    mine = np.zeros(R.shape[1], dtype=bool)
+    mine[touch[:, rank].nonzero()[0]] = True
+    local = np.flatnonzero(mine | (nt > 1))
+    is_if = np.isin(local, iface_glob, assume_unique=True)
+    own = np.where(is_if, 1.0 if rank == 0 else 0.0, 1.0)
+    return LevelShard(cols=local, iface=np.flatnonzero(is_if).astype(np.int32), own=own)
+
+
+def shard_amg(M: AMG, rank: int, world: int):
+    """This rank's slice of an AMG: element range, and per level the columns of R restricted to the local unknowns."""
+    first = M.D_fine[0]
+    p, N = first.active_block.p, first.active_block.N
+    n = p * N
+    parts = element_partition(N, world)
+    e0, e1 = parts[rank]
+    Mrows = slice_amg(M, e0, e1)
+    shards, R_loc = [], []
+    for R, Rr in zip(M.R_fine, Mrows.R_fine):
+        sh = shard_level(R, n, p, parts, rank)
+        shards.append(sh)
+        R_loc.append(sp.csr_matrix(sp.csr_matrix(Rr)[:, sh.cols]))
+    return replace(Mrows, R_fine=R_loc), shards
+
+
+def shard_problem(prob: MGBProblem, rank: int, world: int):
+    """(local MGBProblem, (shards of M[0], shards of M[1]), node index array of the rank)."""
+    first = prob.M[0].D_fine[0]
+    p, N = first.active_block.p, first.active_block.N
+    e0, e1 = element_partition(N, world)[rank]
+    nodes = np.arange(p * e0, p * e1)
+    M0, s0 = shard_amg(prob.M[0], rank, world)
+    M1, s1 = shard_amg(prob.M[1], rank, world)
+    sub = MGBProblem((M0, M1), prob.f[nodes], prob.g[nodes], slice_convex(prob.Q, nodes), M0.geometry)
+    return sub, (s0, s1), nodes
+
+
+class _Reducer:
+    """The reductions mgb_driver's host-side orchestration needs on a sharded problem (phase-I bookkeeping)."""
+
+    def __init__(self, dist, device="cpu"):
+        self.dist, self.device = dist, device
+
+    def _r(self, x, op):
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def max(self, x):
+        return self._r(x, self.dist.ReduceOp.MAX)
+
+    def all(self, flag: bool) -> bool:
+        return self._r(1.0 if flag else 0.0, self.dist.ReduceOp.MIN) > 0.5
+
+
+def make_collective(dist, torch_device: str = "cpu", device_pointers: bool = False):
+    """The all-reduce the library calls (include/mgbhip.h: mgbhip_allreduce_fn) on top of torch.distributed.  Host
+    buffers are wrapped in place; with `device_pointers` (RCCL) large buffers arrive as device pointers and are wrapped
+    through __cuda_array_interface__ -- nothing crosses PCIe."""
+    import ctypes as C
+    import torch
+    from .device import ALLREDUCE_FN
+    errors = []
+
+    class _DevView:
+        def __init__(self, ptr, count):
+            self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+    def _cb(_user, buf, count, op, on_device):
+        try:
+            rop = dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM
+            if on_device:
+                t = torch.as_tensor(_DevView(buf, count), device="cuda")
+                dist.all_reduce(t, op=rop)
+                torch.cuda.current_stream().synchronize()
+            else:
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(int(count),))
+                t = torch.from_numpy(a)
+                if torch_device == "cpu":
+                    dist.all_reduce(t, op=rop)
+                else:                                  # RCCL reduces device tensors only
+                    td = t.to(torch_device)
+                    dist.all_reduce(td, op=rop)
+                    t.copy_(td)
+            return 0
+        except BaseException as e:                     # noqa: BLE001 -- reported by the library as a failed collective
+            errors.append(e)
+            return 1
+    thunk = ALLREDUCE_FN(_cb)
+    thunk.errors = errors
+    return thunk
+
+
+def sharded_mgb_solve(prob: MGBProblem, dist, device_id: int = 0, torch_device: str = "cpu",
+                      device_pointers: bool = False, **kw):
+    """`mgb_solve` of one problem across all ranks of `dist` (torch.distributed, initialised): every rank calls this
+    with the SAME assembled problem, works on its element range and returns the full solution (z gathered at the end).
+    Reference semantics: src/mgb.jl:798-842; the partition: SURVEY.md section 8e."""
+    from .device import DeviceMGBProblem
+    from .solve import MGBSOL, mgb_driver
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sub, shards, nodes = shard_problem(prob, rank, world)
+    coll = make_collective(dist, torch_device, device_pointers)
+    D = DeviceMGBProblem(sub, device_id=device_id, shards=shards, collective=coll, accepts_device_ptr=device_pointers)
+    n_glob = prob.M[0].w.size
+    nz = prob.M[0].w != 0
+    bw = (nz.astype(np.float64) / nz.sum())[nodes]          # the flat barrier average is global (src/convex.jl:279-304)
+    lines = []
+    try:
+        SOL = mgb_driver(D, printlog=lambda *a: lines.append("".join(str(x) for x in a)),
+                         _shard=dict(reduce=_Reducer(dist, torch_device), bw_main=bw, bw_feas=np.full(nodes.size, 1.0 / n_glob)), **kw)
+    except BaseException:
+        if coll.errors:
+            raise coll.errors[0]
+        raise
+    finally:
+        D.close()
+    # gather the rows of z: ranks hold consecutive node ranges
+    parts = [None] * world
+    dist.all_gather_object(parts, SOL["z"])
+    z = np.concatenate(parts, axis=0)
+    return MGBSOL(z, SOL["SOL_feasibility"], SOL["SOL_main"], "\n".join(lines), prob.geometry)

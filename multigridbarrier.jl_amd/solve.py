@@ -192,8 +192,11 @@ def _run_core(P, z, c, opt, what):
 def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[float] = None,
                feasibility_Rmax: float = 1.0 / math.sqrt(EPS), tol=None, kappa=None, maxit=None, max_newton=None,
                stopping_criterion=None, line_search=None, finalize=None, barrier_nodes="default",
-               printlog=lambda *a: None, early_stop=None):
-    """reference: src/mgb.jl:332-584."""
+               printlog=lambda *a: None, early_stop=None, _shard=None):
+    """reference: src/mgb.jl:332-584.  `_shard` (sharded.py): this process holds one rank's slice of a domain-decomposed
+    problem -- maxima / feasibility flags are reduced over ranks and the barrier averages use the global node count."""
+    rmax = (lambda x: _shard["reduce"].max(x)) if _shard else (lambda x: x)
+    rall = (lambda b: _shard["reduce"].all(b)) if _shard else (lambda b: b)
     prob = D.prob
     keep: list = []          # ctypes thunks of user callables: alive until the solves return
     main = D.main
@@ -202,7 +205,7 @@ def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[floa
         t_feasibility = t
     if isinstance(barrier_nodes, str) and barrier_nodes == "default":
         barrier_nodes = M1.w != 0
-    bw_main = _barrier_weights(M1.w, barrier_nodes)
+    bw_main = _shard["bw_main"] if _shard else _barrier_weights(M1.w, barrier_nodes)
     m = M1.w.size
     nD = len(M1.D_fine)
     c0, z0 = prob.f, prob.g
@@ -212,17 +215,19 @@ def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[floa
                   stopping_criterion=stopping_criterion, finalize=finalize)
     SOL_feasibility = None
     F, w_Dz = main.node_barrier(z2, want_Dz=True)
-    if not np.all(np.isfinite(F)):
+    if not rall(bool(np.all(np.isfinite(F)))):
         feas = D.feasibility
+        if _shard:
+            feas.set_barrier_weights(_shard["bw_feas"])
         sl = main.node_slack(z2)
         z1cols = np.concatenate([z0, (2 * np.maximum(sl, 1.0))[:, None]], axis=1)
-        b = 2 * max(1.0, float(z1cols[:, -1].max()))
+        b = 2 * max(1.0, rmax(float(z1cols[:, -1].max())))
         c1 = np.zeros((m, nD + 1 + ncomp))
         c1[:, nD] = 1.0
         z1 = np.ascontiguousarray(z1cols.T).reshape(-1).copy()
         slack_of = lambda z: z[ncomp * m:(ncomp + 1) * m]
-        feasible = lambda z: bool(slack_of(z).max() < 0)
-        Rbox = max(10.0, 10.0 * float(np.abs(z2).max()))
+        feasible = lambda z: bool(rmax(float(slack_of(z).max())) < 0)
+        Rbox = max(10.0, 10.0 * rmax(float(np.abs(z2).max())))
         Rmax = max(float(feasibility_Rmax), Rbox)
         while True:
             printlog("mgb_driver: feasibility phase with bounding box R=", Rbox)
@@ -237,8 +242,8 @@ def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[floa
                 zf = SOL_feasibility["z"]
                 if feasible(zf):
                     break
-                vmax = max(float(np.abs(zf[k * m:(k + 1) * m]).max()) for k in range(ncomp))
-                smax = float(slack_of(zf).max())
+                vmax = rmax(max(float(np.abs(zf[k * m:(k + 1) * m]).max()) for k in range(ncomp)))
+                smax = rmax(float(slack_of(zf).max()))
                 if vmax <= Rbox / 2:
                     raise MGBConvergenceFailure(
                         "The problem appears to be infeasible: the feasibility subproblem converged to a minimizer "

@@ -1,0 +1,187 @@
+"""Row (e): the domain-decomposed Newton solve, world_size 2 over gloo.
+
+CPU part (-m "not gpu"): the decomposition itself -- local unknown sets, interface lists, ownership masks, local R --
+and the algebra the device runs (each rank eliminates its interior, the interface Schur complements are summed, every
+rank solves the interface system and back-substitutes) with the ORACLE as local evaluator: the assembled Newton direction
+must be the single-rank one.
+GPU part (-m gpu): `sharded_mgb_solve` on two processes sharing GPU 0 against the single-rank device solve -- same z
+(1e-8, the reference's cross-backend bar) and the same Newton iteration counts."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(kind):
+    import mgb_amd as m
+    if kind == "fem2d_P2_L3":
+        return m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 3)), p=1.5)
+    if kind == "fem2d_P2_L5":
+        return m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 5)), p=1.0)
+    if kind == "fem3d_L3":
+        return m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 3)), p=1.5)
+    if kind == "phase1":                      # infeasible start: phase I, box, _matched_t hand-off across ranks
+        prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 3)), p=1.5)
+        prob.g[:, 1] = 0.5
+        return prob
+    raise ValueError(kind)
+
+
+def _init(rank, world, port):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU: structure + Schur-complement Newton direction with the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _cpu_worker(rank, world, port, kind, out):
+    _init(rank, world, port)
+    import torch
+    from helpers import stacked
+    from mgb_amd.sharded import shard_problem
+    from oracle import mgb_oracle as O
+    prob = _problem(kind)
+    sub, shards, nodes = shard_problem(prob, rank, world)
+    n_glob = prob.M[0].w.size
+    Mo = O.OracleAMG(sub.M[0])
+    B = O.Barrier(sub.Q, np.full(nodes.size, 1.0 / n_glob))
+    z0, c = stacked(sub.g), 0.1 * sub.f
+    res = {}
+    rng = np.random.default_rng(3)
+    for level in range(len(shards[0])):
+        sh = shards[0][level]
+        m_glob = prob.M[0].R_fine[level].shape[1]
+        s_glob = 1e-3 * rng.standard_normal(m_glob)            # same stream on every rank
+        s = s_glob[sh.cols]
+        R = Mo.R_fine[level]
+        g = B.f1(s, Mo.w, c, R, Mo.D_fine, z0)                 # this rank's partial sums on its local unknowns
+        H = np.asarray(sp.csr_matrix(B.f2(s, Mo.w, c, R, Mo.D_fine, z0)).todense())
+        y = B.f0(s, Mo.w, c, R, Mo.D_fine, z0)
+        I = np.setdiff1d(np.arange(sh.cols.size), sh.iface)
+        G = sh.iface
+        # eliminate the interior, sum the interface Schur complements, solve, back-substitute
+        if I.size:
+            HII_inv_HIG = np.linalg.solve(H[np.ix_(I, I)], H[np.ix_(I, G)])
+            HII_inv_g = np.linalg.solve(H[np.ix_(I, I)], g[I])
+            S = H[np.ix_(G, G)] - H[np.ix_(G, I)] @ HII_inv_HIG
+            r = g[G] - H[np.ix_(G, I)] @ HII_inv_g
+        else:
+            S, r = H[np.ix_(G, G)], g[G]
+        buf = torch.from_numpy(np.concatenate([S.ravel(), r, [y]]))
+        dist.all_reduce(buf)
+        tot = buf.numpy()
+        ng = G.size
+        S, r, y = tot[:ng * ng].reshape(ng, ng), tot[ng * ng:ng * ng + ng], tot[-1]
+        x = np.zeros(sh.cols.size)
+        x[G] = np.linalg.solve(S, r)
+        if I.size:
+            x[I] = HII_inv_g - HII_inv_HIG @ x[G]
+        res[level] = dict(cols=sh.cols, iface=sh.iface, own=sh.own, x=x, y=y, s=s_glob)
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["fem2d_P2_L3", "fem3d_L3"])
+def test_domain_decomposition_reproduces_single_rank_newton_direction_world2(kind):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import stacked
+    from oracle import mgb_oracle as O
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_cpu_worker, args=(world, _free_port(), kind, out), nprocs=world, join=True)
+        res = dict(out)
+    prob = _problem(kind)
+    Mo, B = O.OracleAMG(prob.M[0]), O.Barrier(prob.Q)
+    z0, c = stacked(prob.g), 0.1 * prob.f
+    for level, R in enumerate(Mo.R_fine):
+        a, b = res[0][level], res[1][level]
+        m_J = R.shape[1]
+        # structure: the local sets cover every unknown, interiors are disjoint, interfaces identical, one owner each
+        assert np.array_equal(np.union1d(a["cols"], b["cols"]), np.arange(m_J))
+        ga, gb = a["cols"][a["iface"]], b["cols"][b["iface"]]
+        assert np.array_equal(ga, gb)
+        ia, ib = np.setdiff1d(a["cols"], ga), np.setdiff1d(b["cols"], gb)
+        assert np.intersect1d(ia, ib).size == 0
+        owners = np.zeros(m_J)
+        owners[a["cols"]] += a["own"]
+        owners[b["cols"]] += b["own"]
+        assert np.array_equal(owners, np.ones(m_J))
+        # algebra: the assembled direction is the single-rank one
+        s = a["s"]
+        g = B.f1(s, Mo.w, c, R, Mo.D_fine, z0)
+        H = sp.csc_matrix(B.f2(s, Mo.w, c, R, Mo.D_fine, z0))
+        x_ref = O.solve_symmetric(H, g)
+        x = np.zeros(m_J)
+        x[a["cols"]] = a["x"]
+        x[b["cols"]] = b["x"]
+        assert np.array_equal(a["x"][a["iface"]], b["x"][b["iface"]])         # replicated interface: bit for bit
+        assert np.linalg.norm(x - x_ref) <= 1e-9 * np.linalg.norm(x_ref)
+        assert abs(a["y"] - B.f0(s, Mo.w, c, R, Mo.D_fine, z0)) <= 1e-12 * abs(a["y"])
+    if kind == "fem2d_P2_L3":
+        assert res[0][len(Mo.R_fine) - 1]["iface"].size < 0.1 * Mo.R_fine[-1].shape[1]    # a mesh line
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU: the complete sharded mgb_solve on two ranks sharing the device
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _gpu_worker(rank, world, port, kind, out):
+    _init(rank, world, port)
+    from mgb_amd.sharded import sharded_mgb_solve
+    prob = _problem(kind)
+    sol = sharded_mgb_solve(prob, dist, device_id=0, torch_device="cpu")
+    out[rank] = dict(z=sol.z, its=sol.SOL_main["its"], feas=None if sol.SOL_feasibility is None else sol.SOL_feasibility["its"],
+                     t=sol.SOL_main["ts"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fem2d_P2_L3", "fem2d_P2_L5", "fem3d_L3", "phase1"])
+def test_sharded_mgb_solve_matches_single_rank_world2(kind):
+    import mgb_amd as m
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_gpu_worker, args=(world, _free_port(), kind, out), nprocs=world, join=True)
+        res = dict(out)
+    ref = m.mgb_solve(_problem(kind))
+    for rank in range(world):
+        r = res[rank]
+        assert np.abs(r["z"] - ref.z).max() < 1e-8                          # the reference's criterion (test/test_cuda.jl:51)
+        a, b = np.asarray(r["its"]), np.asarray(ref.SOL_main["its"])
+        # Newton counts: the sums run in another order (interface entries, Schur complements), and the stopping
+        # rules compare quantities at rounding level -- a level solve may stop one iteration earlier or later
+        # (seen: 8/12 instead of 9/13 iterations in the initial centring of the two coarsest levels; in the phase-I case
+        # one t-step whose fine solve needs 8 iterations, the cap of max_newton, converges on one side and bisects the
+        # levels on the other -- same t ramp, same z)
+        assert a.shape == b.shape
+        assert abs(int(a.sum()) - int(b.sum())) <= max(3, 0.05 * b.sum())
+        if kind != "phase1":
+            assert np.abs(a - b).max() <= 3
+        assert np.allclose(r["t"], ref.SOL_main["ts"])
+        assert (r["feas"] is None) == (ref.SOL_feasibility is None)
+    assert np.array_equal(res[0]["z"], res[1]["z"])                         # every rank returns the same solution
