@@ -374,32 +374,55 @@ def make_collective(dist, torch_device: str = "cpu", device_pointers: bool = Fal
     return thunk
 
 
+class ShardedSolver:
+    """One problem resident across all ranks of `dist` (torch.distributed, initialised): every rank constructs this with
+    the SAME assembled problem and keeps its element range on its GPU; `solve()` is `mgb_solve` (reference semantics:
+    src/mgb.jl:798-842; the partition: SURVEY.md section 8e) and returns the full solution on every rank."""
+
+    def __init__(self, prob: MGBProblem, dist, device_id: int = 0, torch_device: str = "cpu", device_pointers: bool = False):
+        from .device import DeviceMGBProblem
+        self.prob, self.dist = prob, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        sub, shards, self.nodes = shard_problem(prob, self.rank, self.world)
+        self.shards = shards
+        self.coll = make_collective(dist, torch_device, device_pointers)
+        self.D = DeviceMGBProblem(sub, device_id=device_id, shards=shards, collective=self.coll, accepts_device_ptr=device_pointers)
+        n_glob = prob.M[0].w.size
+        nz = prob.M[0].w != 0
+        # the flat barrier averages are global (src/convex.jl:279-304)
+        self._shard = dict(reduce=_Reducer(dist, torch_device), bw_main=(nz.astype(np.float64) / nz.sum())[self.nodes],
+                           bw_feas=np.full(self.nodes.size, 1.0 / n_glob))
+
+    def solve_local(self, **kw):
+        """The solve without the final gather: this rank's rows of z (timed loops use this)."""
+        from .solve import mgb_driver
+        lines = []
+        try:
+            SOL = mgb_driver(self.D, printlog=lambda *a: lines.append("".join(str(x) for x in a)), _shard=self._shard, **kw)
+        except BaseException:
+            if self.coll.errors:
+                raise self.coll.errors[0]
+            raise
+        SOL["log"] = "\n".join(lines)
+        return SOL
+
+    def solve(self, **kw):
+        from .solve import MGBSOL
+        SOL = self.solve_local(**kw)
+        parts = [None] * self.world                  # ranks hold consecutive node ranges
+        self.dist.all_gather_object(parts, SOL["z"])
+        return MGBSOL(np.concatenate(parts, axis=0), SOL["SOL_feasibility"], SOL["SOL_main"], SOL["log"], self.prob.geometry)
+
+    def close(self):
+        self.D.close()
+
+
 def sharded_mgb_solve(prob: MGBProblem, dist, device_id: int = 0, torch_device: str = "cpu",
                       device_pointers: bool = False, **kw):
-    """`mgb_solve` of one problem across all ranks of `dist` (torch.distributed, initialised): every rank calls this
-    with the SAME assembled problem, works on its element range and returns the full solution (z gathered at the end).
-    Reference semantics: src/mgb.jl:798-842; the partition: SURVEY.md section 8e."""
-    from .device import DeviceMGBProblem
-    from .solve import MGBSOL, mgb_driver
-    rank, world = dist.get_rank(), dist.get_world_size()
-    sub, shards, nodes = shard_problem(prob, rank, world)
-    coll = make_collective(dist, torch_device, device_pointers)
-    D = DeviceMGBProblem(sub, device_id=device_id, shards=shards, collective=coll, accepts_device_ptr=device_pointers)
-    n_glob = prob.M[0].w.size
-    nz = prob.M[0].w != 0
-    bw = (nz.astype(np.float64) / nz.sum())[nodes]          # the flat barrier average is global (src/convex.jl:279-304)
-    lines = []
+    """`mgb_solve` of one problem across all ranks of `dist`: every rank calls this with the SAME assembled problem and
+    gets the full solution."""
+    S = ShardedSolver(prob, dist, device_id, torch_device, device_pointers)
     try:
-        SOL = mgb_driver(D, printlog=lambda *a: lines.append("".join(str(x) for x in a)),
-                         _shard=dict(reduce=_Reducer(dist, torch_device), bw_main=bw, bw_feas=np.full(nodes.size, 1.0 / n_glob)), **kw)
-    except BaseException:
-        if coll.errors:
-            raise coll.errors[0]
-        raise
+        return S.solve(**kw)
     finally:
-        D.close()
-    # gather the rows of z: ranks hold consecutive node ranges
-    parts = [None] * world
-    dist.all_gather_object(parts, SOL["z"])
-    z = np.concatenate(parts, axis=0)
-    return MGBSOL(z, SOL["SOL_feasibility"], SOL["SOL_main"], "\n".join(lines), prob.geometry)
+        S.close()

@@ -179,7 +179,7 @@ def test_sharded_mgb_solve_matches_single_rank_world2(kind):
         # one t-step whose fine solve needs 8 iterations, the cap of max_newton, converges on one side and bisects the
         # levels on the other -- same t ramp, same z)
         assert a.shape == b.shape
-        assert abs(int(a.sum()) - int(b.sum())) <= max(3, 0.05 * b.sum())
+        assert abs(int(a.sum()) - int(b.sum())) <= max(3, (0.10 if kind == "phase1" else 0.02) * b.sum())
         if kind != "phase1":
             assert np.abs(a - b).max() <= 3
         assert np.allclose(r["t"], ref.SOL_main["ts"])
