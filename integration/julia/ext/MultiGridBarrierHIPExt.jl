@@ -21,7 +21,8 @@ module MultiGridBarrierHIPExt
 using MultiGridBarrier, SparseArrays, LinearAlgebra
 import MultiGridBarrier: Device, HIPDevice, native_to_device, device_to_native, mgb_cleanup, mgb_driver,
                          MGBProblem, MGBSOL, AMG, Convex, BlockDiag, BlockColumn, MGBConvergenceFailure,
-                         default_device!
+                         default_device!, newton, solve, symmetric, mgb_all_isfinite, divide_and_conquer, NoFinalize,
+                         stopping_exact, stopping_inexact, linesearch_backtracking
 
 const libmgbhip = get(ENV, "MGBHIP_LIB", "libmgbhip.so")
 
@@ -153,7 +154,7 @@ function native_to_device(::Type{HIPDevice}, prob::MGBProblem{T}) where {T}
     ctx = Ref{Ptr{Cvoid}}()
     check(@ccall libmgbhip.mgbhip_create(ctx::Ptr{Ptr{Cvoid}}, 0::Cint, C_NULL::Ptr{Cvoid})::Cint)
     img = HIPImage{T}(ctx[], create_problem(ctx[], prob.M[1], prob.Q), C_NULL, prob.M, prob.Q, Any[])
-    finalizer(mgb_cleanup, img)
+    finalizer(mgb_cleanup, img)                                  # safety net only: mgb_driver releases the image itself
     MGBProblem{T}(img, prob.f, prob.g, prob.Q, prob.geometry)   # f, g stay host arrays: mgb_core takes host pointers
 end
 device_to_native(::Type{HIPDevice}, sol::MGBSOL) = sol          # solutions come back as host Arrays already
@@ -164,31 +165,76 @@ function mgb_cleanup(img::HIPImage)                               # plans + fact
     nothing
 end
 mgb_cleanup(::Type{HIPDevice}) = nothing                          # no process-global caches (src/device.jl:92)
-mgb_cleanup(sol::MGBSOL{<:Any,<:Any,<:Any,<:Any,<:Any}) = sol    # the image is released by its finalizer / explicitly below
+# No `mgb_cleanup(::MGBSOL)` method here: the solution holds host arrays only, and the device image -- plans,
+# factorizations, ~3 GB of HBM at L = 9 -- is released deterministically at the end of `mgb_driver` below, on the
+# success path and on the throw path alike (the reference flushes its caches at the same two points, src/mgb.jl:837-840).
 
 feasibility_handle!(img::HIPImage) = img.feas != C_NULL ? img.feas :
     (img.feas = create_problem(img.ctx, img.M[2], img.Q; feasibility=true, NC=length(img.M[1].D_fine) + 1, share=img.main))
 
 # ---- mgb_core through the C ABI -----------------------------------------------------------------------
-function options(h, n; tol, t, kappa, maxit, max_newton, early_stop::Int, finalize::Bool)
+# User callables cross the C ABI as plain C function pointers + a `user` pointer to this state object (no closure
+# trampolines: works on every platform).  An exception raised by the callable is kept, the library is told to stop
+# (converged / early stop = true), and hip_mgb_core rethrows it -- in the reference it would propagate out of newton.
+mutable struct CallbackState
+    stop::Any            # stopping_criterion(ymin, ynext, gmin, gnext, n, ndecmin, ndec) or nothing
+    early::Any           # early_stop(z) / early_stop(z, t) or nothing
+    zlen::Int
+    err::Any
+end
+function stop_thunk(ymin::Cdouble, ynext::Cdouble, gmin::Cdouble, gn::Cdouble, ndecmin::Cdouble, ndec::Cdouble,
+                    user::Ptr{Cvoid})::Cint
+    st = unsafe_pointer_to_objref(user)::CallbackState
+    st.err === nothing || return Cint(1)
+    try
+        # gnext arrives as its norm (the vector stays on the device): a one-element vector keeps `norm(gnext)` right
+        return Cint(st.stop(ymin, ynext, gmin, [gn], nothing, ndecmin, ndec) ? 1 : 0)
+    catch e
+        st.err = e
+        return Cint(1)
+    end
+end
+function early_thunk(z::Ptr{Cdouble}, t::Cdouble, user::Ptr{Cvoid})::Cint
+    st = unsafe_pointer_to_objref(user)::CallbackState
+    st.err === nothing || return Cint(1)
+    st.early === nothing && return Cint(0)
+    try
+        zz = copy(unsafe_wrap(Array, z, st.zlen))
+        return Cint((applicable(st.early, zz, t) ? st.early(zz, t) : st.early(zz)) ? 1 : 0)
+    catch e
+        st.err = e
+        return Cint(1)
+    end
+end
+
+function options(h, n; tol, t, kappa, maxit, max_newton, early_stop::Int, finalize::Bool, state::Union{Nothing,CallbackState}=nothing)
     o = COptions()
     @ccall libmgbhip.mgbhip_default_options(o::Ref{COptions}, n::Int64)::Cvoid
     tol === nothing || (o.tol = tol); o.t = t
     kappa === nothing || (o.kappa = kappa); maxit === nothing || (o.maxit = maxit)
     max_newton === nothing || (o.max_newton = max_newton)
     o.finalize = finalize ? 1 : 0; o.early_stop = early_stop
+    if state !== nothing
+        o.user = pointer_from_objref(state)
+        state.stop === nothing || (o.stopping_criterion =
+            @cfunction(stop_thunk, Cint, (Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cvoid})))
+        # installed whenever a callable is present: a raising stopping rule must be able to end the t-ramp too
+        o.early_stop_fn = @cfunction(early_thunk, Cint, (Ptr{Cdouble}, Cdouble, Ptr{Cvoid}))
+    end
     o
 end
 
-function hip_mgb_core(h::Ptr{Cvoid}, L::Int, z::Vector{Float64}, c::Matrix{Float64}, o::COptions)
+function hip_mgb_core(h::Ptr{Cvoid}, L::Int, z::Vector{Float64}, c::Matrix{Float64}, o::COptions;
+                      state::Union{Nothing,CallbackState}=nothing)
     cap = 4096
     its = zeros(Int64, L, cap); ts = zeros(cap); kap = zeros(cap); tms = zeros(cap); cdz = zeros(cap)
     r = CCoreResult(); r.cap_steps = cap
-    GC.@preserve its ts kap tms cdz z c begin
+    GC.@preserve its ts kap tms cdz z c state begin
         r.its = pointer(its); r.ts = pointer(ts); r.kappas = pointer(kap); r.times = pointer(tms); r.c_dot_Dz = pointer(cdz)
         rc = @ccall libmgbhip.mgbhip_mgb_core(h::Ptr{Cvoid}, z::Ptr{Float64}, c::Ptr{Float64}, o::Ref{COptions},
                                               r::Ref{CCoreResult})::Cint
     end
+    state !== nothing && state.err !== nothing && throw(state.err)  # a user callable raised: propagate, like the reference
     if rc == 5                                                       # MGBHIP_ERR_CONVERGENCE
         code = r.failure_code == 2 ? :iteration_limit : :stall
         msg = (r.k == 1 && code === :stall && r.t_final == o.t) ?
@@ -206,12 +252,144 @@ node_barrier(h, z, n, nD) = (F = zeros(n); Dz = zeros(n, nD);
     check(@ccall libmgbhip.mgbhip_node_barrier(h::Ptr{Cvoid}, z::Ptr{Float64}, F::Ptr{Float64}, Dz::Ptr{Float64})::Cint); (F, Dz))
 node_slack(h, z, n) = (s = zeros(n); check(@ccall libmgbhip.mgbhip_node_slack(h::Ptr{Cvoid}, z::Ptr{Float64}, s::Ptr{Float64})::Cint); s)
 
+# ---- device vectors + the reference's generic `newton` on them (custom line_search / finalize closures) -----------
+# `newton` (src/newton.jl:227-287) needs from its vector type: +, -, scalar *, dot, norm, mgb_all_isfinite; from its
+# matrix type: symmetric(H) and solve(H, g).  HIPVec wraps an mgbhip_vec, HIPHessian is a token for "the H that
+# mgbhip_f2_d left assembled at this level".  User line searches receive HIPVecs and the closures F0 / F1.
+mutable struct HIPVec
+    h::Ptr{Cvoid}
+    ctx::Ptr{Cvoid}
+    n::Int
+    function HIPVec(ctx::Ptr{Cvoid}, n::Integer)
+        r = Ref{Ptr{Cvoid}}()
+        check(@ccall libmgbhip.mgbhip_vec_alloc(ctx::Ptr{Cvoid}, Int64(n)::Int64, r::Ptr{Ptr{Cvoid}})::Cint)
+        v = new(r[], ctx, Int(n))
+        finalizer(free!, v)
+        v
+    end
+end
+free!(v::HIPVec) = (v.h != C_NULL && (@ccall libmgbhip.mgbhip_vec_free(v.h::Ptr{Cvoid})::Cint; v.h = C_NULL); nothing)
+function HIPVec(ctx::Ptr{Cvoid}, a::AbstractVector{Float64})
+    v = HIPVec(ctx, length(a)); b = Vector{Float64}(a)
+    GC.@preserve b check(@ccall libmgbhip.mgbhip_vec_upload(v.h::Ptr{Cvoid}, b::Ptr{Float64}, Int64(length(b))::Int64)::Cint)
+    v
+end
+Base.length(v::HIPVec) = v.n
+Base.Array(v::HIPVec) = (a = zeros(v.n); check(@ccall libmgbhip.mgbhip_vec_download(v.h::Ptr{Cvoid}, a::Ptr{Float64}, Int64(v.n)::Int64)::Cint); a)
+Base.copy(v::HIPVec) = (w = HIPVec(v.ctx, v.n); check(@ccall libmgbhip.mgbhip_vec_copy(w.h::Ptr{Cvoid}, v.h::Ptr{Cvoid})::Cint); w)
+axpy!(a::Real, x::HIPVec, y::HIPVec) = (check(@ccall libmgbhip.mgbhip_vec_axpy(Float64(a)::Float64, x.h::Ptr{Cvoid}, y.h::Ptr{Cvoid})::Cint); y)
+Base.:+(a::HIPVec, b::HIPVec) = axpy!(1.0, b, copy(a))
+Base.:-(a::HIPVec, b::HIPVec) = axpy!(-1.0, b, copy(a))
+Base.:*(s::Real, v::HIPVec) = (w = copy(v); check(@ccall libmgbhip.mgbhip_vec_scale(Float64(s)::Float64, w.h::Ptr{Cvoid})::Cint); w)
+Base.:*(v::HIPVec, s::Real) = s * v
+Base.:-(v::HIPVec) = -1.0 * v
+LinearAlgebra.dot(a::HIPVec, b::HIPVec) = (r = Ref{Float64}(); check(@ccall libmgbhip.mgbhip_vec_dot(a.h::Ptr{Cvoid}, b.h::Ptr{Cvoid}, r::Ptr{Float64})::Cint); r[])
+LinearAlgebra.norm(a::HIPVec) = (r = Ref{Float64}(); check(@ccall libmgbhip.mgbhip_vec_norm(a.h::Ptr{Cvoid}, r::Ptr{Float64})::Cint); r[])
+mgb_all_isfinite(a::HIPVec) = (r = Ref{Int32}(); check(@ccall libmgbhip.mgbhip_vec_isfinite(a.h::Ptr{Cvoid}, r::Ptr{Int32})::Cint); r[] != 0)
+
+struct HIPHessian
+    prob::Ptr{Cvoid}
+    level::Int32
+    ctx::Ptr{Cvoid}
+end
+symmetric(H::HIPHessian) = H
+function solve(H::HIPHessian, g::HIPVec)
+    x = HIPVec(H.ctx, g.n)
+    check(@ccall libmgbhip.mgbhip_solve_d(H.prob::Ptr{Cvoid}, H.level::Int32, g.h::Ptr{Cvoid}, x.h::Ptr{Cvoid})::Cint)
+    x
+end
+
+# mgb_step + mgb_core (src/mgb.jl:16-183) on device vectors, for the keyword arguments the resident ramp cannot take.
+function generic_mgb_core(img::HIPImage{T}, h::Ptr{Cvoid}, z0::Vector{T}, c0::Matrix{T}; tol, t, kappa, maxit, max_newton,
+                          finalize, stopping_criterion, early_stop, line_search, printlog) where {T}
+    M1 = img.M[1]
+    n, L = length(M1.w), length(M1.R_fine)
+    tol = something(tol, sqrt(eps(T))); kappa = T(something(kappa, 10)); maxit = something(maxit, 10000)
+    max_newton = something(max_newton, Int(ceil(log2(-log2(eps(T)))) + 2))
+    sc = something(stopping_criterion, stopping_inexact(T(0.25) / sqrt(T(n)), T(0.9)))
+    ls = something(line_search, linesearch_backtracking(T))
+    fin = finalize === true ? stopping_exact(T(0.9)) : (finalize === false ? NoFinalize() : finalize)
+    stop_early = something(early_stop, z -> false)
+    estop(z, tt) = (zz = Array(z); applicable(stop_early, zz, tt) ? stop_early(zz, tt) : stop_early(zz))
+    z = HIPVec(img.ctx, z0)
+    sizes = [Int(@ccall libmgbhip.mgbhip_level_size(h::Ptr{Cvoid}, Int32(J - 1)::Int32)::Int64) for J in 1:L]
+    function step(cvec::HIPVec, finalize_now, initial_step)
+        its = zeros(Int, L)
+        function eta(j, J, crit, mi)
+            zJ = copy(z)                                                 # the closures capture a snapshot (src/mgb.jl:48)
+            lev = Int32(J - 1)
+            F0(s) = (r = Ref{Float64}(); check(@ccall libmgbhip.mgbhip_f0_d(h::Ptr{Cvoid}, lev::Int32, s.h::Ptr{Cvoid},
+                     cvec.h::Ptr{Cvoid}, zJ.h::Ptr{Cvoid}, r::Ptr{Float64})::Cint); r[])
+            F1(s) = (gv = HIPVec(img.ctx, sizes[J]); check(@ccall libmgbhip.mgbhip_f1_d(h::Ptr{Cvoid}, lev::Int32, s.h::Ptr{Cvoid},
+                     cvec.h::Ptr{Cvoid}, zJ.h::Ptr{Cvoid}, gv.h::Ptr{Cvoid})::Cint); gv)
+            F2(s) = (check(@ccall libmgbhip.mgbhip_f2_d(h::Ptr{Cvoid}, lev::Int32, s.h::Ptr{Cvoid}, cvec.h::Ptr{Cvoid},
+                     zJ.h::Ptr{Cvoid})::Cint); HIPHessian(h, lev, img.ctx))
+            SOL = newton(HIPHessian, T, F0, F1, F2, HIPVec(img.ctx, sizes[J]); maxit=mi, stopping_criterion=crit,
+                         line_search=ls, printlog)
+            its[J] += SOL.k
+            SOL.converged && check(@ccall libmgbhip.mgbhip_prolong_add(h::Ptr{Cvoid}, lev::Int32, SOL.x.h::Ptr{Cvoid}, z.h::Ptr{Cvoid})::Cint)
+            SOL.converged
+        end
+        mn(j, J) = (initial_step && J - j == 1) ? maxit : max_newton
+        zsave = copy(z)
+        converged = divide_and_conquer((j, J) -> eta(j, J, sc, mn(j, J)), 0, L)
+        if finalize_now && !(fin isa NoFinalize)
+            converged = eta(L - 1, L, fin, maxit) && converged
+        end
+        converged || (z = zsave)                                       # z = SOL.z only on success (src/mgb.jl:150-157)
+        (; its, converged)
+    end
+    cdev(tt) = HIPVec(img.ctx, vec(tt .* c0))
+    target = 1 / tol; kappa0 = kappa; t = T(t)
+    itsall = Vector{Vector{Int}}(); ts = T[]; kappas = T[]
+    t_begin = time()
+    S = step(cdev(t), t >= target, true)
+    S.converged || throw(MGBConvergenceFailure("Initial centering failed in mgb_solve at t=$t, tol=$tol, maxit=$maxit.", :stall))
+    push!(itsall, S.its); push!(ts, t); push!(kappas, kappa)
+    k = 1
+    while t < target && kappa > 1 && k < maxit && !estop(z, t)
+        k += 1; acc = zeros(Int, L)
+        while kappa > 1
+            t1 = kappa * t
+            S = step(cdev(t1), t1 >= target, false); acc .+= S.its
+            if S.converged
+                maximum(S.its) <= max_newton * 0.5 && (kappa = min(kappa0, kappa^2))
+                t = t1; break
+            end
+            kappa = sqrt(kappa)
+        end
+        push!(itsall, acc); push!(ts, t); push!(kappas, kappa)
+    end
+    (t >= target || estop(z, t)) || throw(MGBConvergenceFailure(
+        "Convergence failure in mgb_solve at t=$t, k=$k, kappa=$kappa, tol=$tol, maxit=$maxit.", kappa <= 1 ? :stall : :iteration_limit))
+    t_end = time()
+    (; z = Array(z), its = reduce(hcat, itsall), ts, kappas, times = T[], c_dot_Dz = T[], t_begin, t_end,
+       t_elapsed = t_end - t_begin, c = c0)
+end
+
 # ---- mgb_driver for the device image: src/mgb.jl:332-584 restated around the C entry points ----------
-function mgb_driver(img::HIPImage{T}, f::Matrix{T}, g::Matrix{T}, Q::Convex{T};
-                    t=T(0.1), t_feasibility=t, feasibility_Rmax=one(T) / sqrt(eps(T)), progress=x -> nothing,
-                    printlog=(args...) -> nothing, tol=nothing, kappa=nothing, maxit=nothing, max_newton=nothing,
-                    finalize=true, barrier_nodes=nothing, rest...) where {T}
-    isempty(rest) || error("HIPDevice: keyword(s) $(keys(rest)) need the fine-grained device-vector API (INTEGRATION.md section 2b)")
+function mgb_driver(img::HIPImage{T}, f::Matrix{T}, g::Matrix{T}, Q::Convex{T}; keep_image::Bool=false, kw...) where {T}
+    try
+        return hip_mgb_driver(img, f, g, Q; kw...)
+    finally
+        # The reference flushes its plan / factorization caches after every solve, on the success and on the throw
+        # path (src/mgb.jl:837-840).  Here they live in the image: release it now instead of waiting for the GC
+        # (`keep_image=true` keeps it resident for a caller that re-solves, e.g. a time-stepping loop).
+        keep_image || mgb_cleanup(img)
+    end
+end
+
+function hip_mgb_driver(img::HIPImage{T}, f::Matrix{T}, g::Matrix{T}, Q::Convex{T};
+                        t=T(0.1), t_feasibility=t, feasibility_Rmax=one(T) / sqrt(eps(T)), progress=x -> nothing,
+                        printlog=(args...) -> nothing, tol=nothing, kappa=nothing, maxit=nothing, max_newton=nothing,
+                        finalize=true, barrier_nodes=nothing, stopping_criterion=nothing, early_stop=nothing,
+                        line_search=nothing, rest...) where {T}
+    isempty(rest) || error("HIPDevice: unsupported keyword(s) $(keys(rest))")
+    # `finalize`: true / false / NoFinalize() / a stopping_exact-style closure is not representable in mgbhip_options
+    # beyond on/off + theta; closures other than the default run on the device-vector path below
+    generic = line_search !== nothing || !(finalize isa Bool)
+    state = (stopping_criterion === nothing && early_stop === nothing) ? nothing :
+            CallbackState(stopping_criterion, early_stop, size(g, 2) * size(g, 1), nothing)
     M1 = img.M[1]
     m, nD, ncomp = length(M1.w), length(M1.D_fine), size(g, 2)
     L = length(M1.R_fine)
@@ -234,8 +412,9 @@ function mgb_driver(img::HIPImage{T}, f::Matrix{T}, g::Matrix{T}, Q::Convex{T};
             check(@ccall libmgbhip.mgbhip_problem_set_box(feas::Ptr{Cvoid}, b::Float64, Rbox::Float64)::Cint)
             failure = nothing
             try
-                o = options(feas, m; tol, t=t_feasibility, kappa, maxit, max_newton, early_stop=1, finalize)
-                SOL_feasibility = hip_mgb_core(feas, L, copy(z1), c1, o)
+                fstate = stopping_criterion === nothing ? nothing : CallbackState(stopping_criterion, nothing, length(z1), nothing)
+                o = options(feas, m; tol, t=t_feasibility, kappa, maxit, max_newton, early_stop=1, finalize=(finalize === true), state=fstate)
+                SOL_feasibility = hip_mgb_core(feas, L, copy(z1), c1, o; state=fstate)
             catch e
                 e isa InterruptException && rethrow(); failure = e      # each round is a probe (src/mgb.jl:505-515)
             end
@@ -260,8 +439,15 @@ function mgb_driver(img::HIPImage{T}, f::Matrix{T}, g::Matrix{T}, Q::Convex{T};
         t = min(t, tm[])
     end
     check(@ccall libmgbhip.mgbhip_problem_set_barrier_weights(img.main::Ptr{Cvoid}, bw::Ptr{Float64})::Cint)
-    o = options(img.main, m; tol, t, kappa, maxit, max_newton, early_stop=0, finalize)
-    SOL_main = hip_mgb_core(img.main, L, z2, f, o)
+    SOL_main = if generic
+        # a user line search (or finalize closure) needs the vectors: the reference's own `newton` runs on device
+        # vectors through the fine-grained entry points (INTEGRATION.md section 2b)
+        generic_mgb_core(img, img.main, z2, f; tol, t, kappa, maxit, max_newton, finalize, stopping_criterion, early_stop,
+                         line_search, printlog)
+    else
+        o = options(img.main, m; tol, t, kappa, maxit, max_newton, early_stop=0, finalize, state)
+        hip_mgb_core(img.main, L, z2, f, o; state)
+    end
     progress(1.0)
     (; z = reshape(SOL_main.z, m, ncomp), SOL_feasibility, SOL_main)
 end
