@@ -718,9 +718,15 @@ __global__ __launch_bounds__(256) void elem_f01_fast(const ElemParams Pm) {
 // absolute error of hundreds in a matrix whose smallest eigenvalue is 34: H comes out indefinite by summation
 // noise alone (tests/dev/logs/gpu_coarse_noise_probe_L8_p1.5.txt).  TwoSum accumulation (Knuth) carries the rounding
 // error of every addition in a second word: the sum is the correctly rounded one to a few ulps, whatever the order.
+// Used by the gather_assemble_* kernels and the long-row restrictions.  (At cond(H) ~ 1e15 the sign of lambda^2 also
+// depends on the rounding of the per-node terms themselves, which no summation scheme removes: DESIGN.md section 5.)
 struct DSum {
     double s = 0.0, c = 0.0;
     __device__ __forceinline__ void add(double x) {
+#ifdef MGB_PLAIN_SUMS
+        s += x;
+        return;
+#endif
         const double t = s + x;
         const double bp = t - s;
         c += (s - (t - bp)) + (x - bp);
@@ -996,15 +1002,27 @@ __global__ __launch_bounds__(256) void gather_shared_kernel(int64_t nshared, con
     if (i >= nshared) return;
     const int32_t q = sh_q[i];
     const int32_t beg = cptr[q], end = cptr[q + 1];
-    double s = 0.0;
+    if (end - beg <= 4) {                                    // same rule and order as gather_assemble_kernel: bitwise the same sums
+        double a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = (beg + u < end) ? slab[cidx[beg + u]] : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (beg + u < end) s += a[u];
+        out[i] = s;
+        return;
+    }
+    DSum acc;
     for (int32_t t = beg; t < end; t += 4) {                 // four contributions in flight, added in list order
         double a[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) a[u] = (t + u < end) ? slab[cidx[t + u]] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s += a[u];
+        for (int u = 0; u < 4; ++u)
+            if (t + u < end) acc.add(a[u]);
     }
-    out[i] = s;
+    out[i] = acc.value();
 }
 
 // Long contribution lists (coarse levels: few unknowns, every element contributes): one wave per

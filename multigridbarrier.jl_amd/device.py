@@ -119,8 +119,9 @@ EXPORTS = [
 
 
 def library_path() -> str:
+    """The in-tree build; MGBHIP_LIB overrides it (A/B builds of the same library, like the Julia glue's variable)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    return os.path.join(here, "lib", "libmgbhip.so")
+    return os.environ.get("MGBHIP_LIB") or os.path.join(here, "lib", "libmgbhip.so")
 
 
 _LIB = None

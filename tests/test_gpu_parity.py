@@ -4,6 +4,8 @@ and against the oracle; size-independent properties at BASELINE config-2 size.
 
 Tolerances: north_star asks for 1e-10 relative per kernel (fp64); the end-to-end bar is the
 reference's own cross-backend criterion max|z_cpu - z_dev| < 1e-8 (test/test_cuda.jl:51)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -565,30 +567,47 @@ def test_c_dot_Dz_diagnostic_matches_oracle():
     assert np.isclose(a[-1], float(np.sum(Mo.w[:, None] * prob.f * Dz)), rtol=1e-10)
 
 
-def test_default_hierarchy_initial_centring_at_L8_is_pinned():
-    """The reference-default ladder `amg_ruge_stuben(max_coarse=2)` coarsens the P1 corner problem to
-    1-4 unknowns.  With this package's Ruge-Stueben restatement the p = 1 solve converges on it at
-    L = 8, while for p = 1.5 the initial centring does not: in the 4-unknown space Newton creeps along the
-    barrier wall (lambda^2 ~ 1e-5, objective gains ~ 1e-5 per iteration) until roundoff makes lambda^2 <= 0.
-    WHEN that happens is noise: the device stops after a few dozen iterations, the oracle -- same algorithm,
-    NumPy arithmetic -- may creep for hundreds (a 1-ulp change of the hierarchy operators moved it from
-    dozens to > 340).  Pinned here: the device reports the stall, and the oracle makes no more progress than
-    the device did within a budget of iterations.  DESIGN.md section 5 records the evidence and why the P
-    entries of the third-party AMG are unpinned."""
+# Full-length oracle runs on the reference-default ladder (tests/dev/logs/, scripts tests/dev/oracle_*.py; hours of
+# NumPy at these sizes, so the counts are pinned here and the logs committed):
+#   L = 8, p = 1.5: the initial centring ends in the 4-unknown space, where Newton creeps along the cone's wall for
+#                   ORACLE_L8_LEVEL0 iterations (cond(H) ~ 1e14) and converges; the solve then completes.
+#   L = 9, p = 1.5: in the 2-unknown space H (eigenvalues -1.3e2 .. 4.1e16) comes out indefinite after 28 iterations:
+#                   lambda^2 = -1.1e-3, "Initial centering failed" -- the algorithm's own limit in fp64.
+ORACLE_L8_LEVEL0 = (950, 1000)        # tests/dev/logs/oracle_fem2d_P2_L8_p1.5_default.log: converged between these k
+ORACLE_L9_FAIL_K = 28                 # tests/dev/logs/oracle_coarsest_newton_L9_p1.5.log
+
+
+def test_default_hierarchy_p15_same_outcome_as_oracle_at_L8_and_L9():
+    """North-star problem fem2d_P2 p = 1.5 on the reference-default ladder `amg_ruge_stuben(max_coarse=2)`
+    (src/fem2d_P2.jl:401).  Round 2 stalled at L = 8 where the oracle, run to completion in round 3, converges: the
+    coarse assembly summed 131 072 element contributions into entries of size 1e16 with a plain running sum and lost the
+    soft part of H to summation noise (H indefinite, lambda^2 < 0 after 43 iterations).  With compensated sums
+    (kernels.hip: DSum) the device follows the oracle: same outcome, iteration counts within a few per cent."""
     from mgb_amd.solve import MGBConvergenceFailure
     prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 8)), p=1.5)
     assert [R.shape[1] for R in prob.M[0].R_fine][:3] == [4, 15, 66]
+    sol = m.mgb_solve(prob)
+    its = sol.SOL_main["its"]
+    assert np.isfinite(sol.z).all() and sol.SOL_main["ts"][-1] >= 1.0 / np.sqrt(np.finfo(float).eps)
+    lo, hi = ORACLE_L8_LEVEL0
+    assert 0.95 * lo <= its[0, 0] <= 1.05 * hi, its[:, 0]          # the creeping solve in the 4-unknown space
+    assert its.sum() - its[0, 0] < 400                              # the rest of the solve is an ordinary one
+    # L = 9: both stop in the coarsest space after a few dozen iterations
+    prob9 = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 9)), p=1.5)
+    assert [R.shape[1] for R in prob9.M[0].R_fine][:3] == [2, 7, 18]
     with pytest.raises(MGBConvergenceFailure) as ed:
-        m.mgb_solve(prob)
+        m.mgb_solve(prob9)
     assert ed.value.code == "stall" and "Initial centering failed" in str(ed.value)
-    st = {"y_hist": [], "max_its": 100}
-    with pytest.raises((O.MGBConvergenceFailure, TimeoutError)):
-        O.mgb_solve(prob, stats=st)
-    ys = np.array(st["y_hist"])
-    assert ys.size >= 30                       # still in the first (coarsest-level) Newton solve: no convergence
-    tail = ys[-20:]
-    assert np.all(np.diff(tail) <= 0) and (tail[0] - tail[-1]) < 1e-3 * abs(tail[-1])      # creeping, like the device
-    # the smallest deviation that converges: max_coarse = 10 (coarsest space 15 unknowns)
+    if os.environ.get("MGB_SLOW_TESTS") == "1":                     # ~5 minutes of NumPy: the oracle's side of the L = 9 claim
+        import math
+        Mo, B = O.OracleAMG(prob9.M[0]), O.Barrier(prob9.Q)
+        z0, c, R = stacked(prob9.g), 0.1 * prob9.f, O.OracleAMG(prob9.M[0]).R_fine[0]
+        S = O.newton(lambda s: B.f0(s, Mo.w, c, R, Mo.D_fine, z0), lambda s: B.f1(s, Mo.w, c, R, Mo.D_fine, z0),
+                     lambda s: B.f2(s, Mo.w, c, R, Mo.D_fine, z0), np.zeros(R.shape[1]), maxit=10000,
+                     stopping_criterion=O.stopping_inexact(0.25 / math.sqrt(Mo.w.size), 0.9),
+                     line_search=O.linesearch_backtracking())
+        assert not S["converged"] and abs(S["k"] - ORACLE_L9_FAIL_K) <= 5
+    # max_coarse = 10 (coarsest space 15 unknowns) converges at L = 9: what the bench's p = 1.5 line runs
     prob10 = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 8), prolongator=m.amg_ruge_stuben(max_coarse=10)), p=1.5)
     sol = m.mgb_solve(prob10)
     assert np.isfinite(sol.z).all() and int(sol.SOL_main["its"].sum()) < 400
@@ -663,10 +682,13 @@ def test_config4_default_start_phase1_full_size():
     """BASELINE configs[3] at full size from the DEFAULT (infeasible) start: fem3d() Q1 p = 4, L = 6 -- phase I with
     box escalation, `_matched_t` hand-off, main ramp -- checked by invariants (no oracle run at 262 144 nodes):
     strictly feasible result, Dirichlet data exact, and a second solve on the resident image is bitwise identical
-    with the same iteration counts.  Hierarchy: max_coarse=300 (the reference default ladder stalls in phase I's
-    initial centring here, like the p = 1.5 case pinned above)."""
+    with the same iteration counts.  Hierarchy: max_coarse=500 (coarsest space 861 unknowns, 1 402 iterations).  On the
+    reference-default ladder phase I's initial centring ends with lambda^2 <= 0 in the coarsest space on the device and
+    in the oracle alike; with max_coarse=300 it creeps for 9 000 iterations in a 145-unknown space at cond(H) ~ 1e15,
+    where the outcome is a matter of rounding (device 9 357 / oracle 9 359 iterations with plain restriction sums; H
+    indefinite at iteration 5 065 with compensated ones) -- DESIGN.md section 5."""
     from mgb_amd.solve import mgb_driver
-    prob = m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 6), prolongator=m.amg_ruge_stuben(max_coarse=300)), p=4.0)
+    prob = m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 6), prolongator=m.amg_ruge_stuben(max_coarse=500)), p=4.0)
     n = prob.M[0].w.size
     assert n == 262144
     sol = m.mgb_solve(prob, keep_device=True)

@@ -15,6 +15,10 @@ P.reset_stage_timers(True)
 for _ in range(reps):
     P.f0(J, s, c, z0); P.f1(J, s, c, z0); P.f2(J, s, c, z0, want_matrix=False)
 B = dict(f0=219, f1=231 - 11.4, restrict=11.4 * 2 + 24, f2=347, assemble=488)   # SURVEY section 8(d) bytes / node
+# the Newton loop's own f2: from the second call on the element kernel condenses the leaves (kernels.hpp)
+if os.environ.get("MGB_NEWTON_F2", "1") == "1":
+    for _ in range(reps + 1):
+        P.newton_direction(J, s, c, z0)
 for st in ('f0', 'f1', 'restrict', 'f2', 'assemble'):
     ms, cnt = P.stage_ms(st)
     us = 1e3 * ms / max(cnt, 1)
