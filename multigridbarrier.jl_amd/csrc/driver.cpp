@@ -92,10 +92,11 @@ bool trial_values(NewtonCtx& C, double& ynext, double& gnorm_next, int32_t* move
     mgbhip_problem* P = C.P;
     hipStream_t st = P->stream();
     P->eval_f01_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c, P->d_gn.p, P->sharded() ? P->d_gnpart.p : nullptr);
-    launch_vec_stats(P->d_gn.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st, P->own_mask(C.level));
-    MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d, P->d_scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-    MGB_HIP_CHECK(hipMemcpyAsync(P->pin.i, P->d_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // value (d_scal[0]), |g|^2, non-finite count and the step kernel's "moved" flag in ONE read-back
+    launch_vec_stats(P->d_gn.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st, P->own_mask(C.level), P->d_flag.p, 1);
+    MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d, P->d_scal.p, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
     MGB_HIP_CHECK(hipStreamSynchronize(st));
+    P->pin.i[0] = P->pin.d[4] != 0.0 ? 1 : 0;
     if (P->sharded()) {              // value, |g|^2, non-finite count and the "moved" flag in one sum over ranks
         P->pin.d[1] = (double)P->pin.i[0];
         P->allreduce_host(P->pin.d, 4, 0);
@@ -216,10 +217,12 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
             P->factor(C.level, C.rhs_of_g());               // the gradient rides along: no forward sweep afterwards
             P->trisolve_carried(C.level, P->d_nv.p);
             // pivot flag, direction statistics and lambda^2 = <g, n> in one round trip
-            launch_dir_stats(P->d_nv.p, P->d_g.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st, P->own_mask(C.level));
-            MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-            L.solver.status_async(P->pin.i + 1, st);
+            launch_dir_stats(P->d_nv.p, P->d_g.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st, P->own_mask(C.level),
+                             L.solver.status_flags(), 2);
+            MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
             MGB_HIP_CHECK(hipStreamSynchronize(st));
+            P->pin.i[1] = P->pin.d[5] != 0.0 ? 1 : 0;
+            P->pin.i[2] = P->pin.d[6] != 0.0 ? 1 : 0;
             fstatus = MfSolver::status_from(P->pin.i + 1, L.solver.factored_condensed);
             if (P->sharded()) {          // every rank must take the same branch: the pivot flag travels with the sums
                 P->pin.d[5] = fstatus != MGBHIP_OK ? 1.0 : 0.0;

@@ -822,9 +822,12 @@ __global__ __launch_bounds__(256) void dir_stats_kernel(const double* __restrict
 }
 
 __global__ __launch_bounds__(256) void reduce2_kernel(const double* __restrict__ partials, int nb,
-                                                      double* __restrict__ out, int nout) {
+                                                      double* __restrict__ out, int nout,
+                                                      const int32_t* __restrict__ ints, int nints) {
     __shared__ double red[256];
     const int tid = threadIdx.x;
+    // device flags the host wants in the same read-back (a pivot status, a "moved" flag) ride behind the sums as doubles
+    if (tid < nints) out[nout + tid] = (double)ints[tid];
     for (int o = 0; o < nout; ++o) {
         double s = 0.0;
         for (int i = tid; i < nb; i += 256) s += partials[o * nb + i];
@@ -1556,25 +1559,26 @@ void launch_index_scatter(const double* in, const int32_t* idx, int64_t cnt, dou
     MGB_HIP_CHECK(hipGetLastError());
 }
 
-void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st, const double* mask) {
+void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st, const double* mask,
+                      const int32_t* ints, int nints) {
     const int nb = reduce_blocks(n);
     hipLaunchKernelGGL(block_reduce_kernel<1>, dim3(nb), dim3(256), 0, st, v, (const double*)nullptr, n, scratch, mask);
-    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats, 2);
+    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats, 2, ints, nints);
     MGB_HIP_CHECK(hipGetLastError());
 }
 
 void launch_dir_stats(const double* v, const double* g, int64_t n, double* scratch, double* stats3, hipStream_t st,
-                      const double* mask) {
+                      const double* mask, const int32_t* ints, int nints) {
     const int nb = reduce_blocks(n);
     hipLaunchKernelGGL(dir_stats_kernel, dim3(nb), dim3(256), 0, st, v, g, n, scratch, mask);
-    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats3, 3);
+    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats3, 3, ints, nints);
     MGB_HIP_CHECK(hipGetLastError());
 }
 
 void launch_dot(const double* a, const double* b, int64_t n, double* scratch, double* out, hipStream_t st, const double* mask) {
     const int nb = reduce_blocks(n);
     hipLaunchKernelGGL(block_reduce_kernel<0>, dim3(nb), dim3(256), 0, st, a, b, n, scratch, mask);
-    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, out, 1);
+    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, out, 1, (const int32_t*)nullptr, 0);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

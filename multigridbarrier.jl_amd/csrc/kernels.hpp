@@ -81,10 +81,12 @@ void launch_elem(const ElemParams& P, int mode, hipStream_t st);
 void launch_reduce_partials(const double* partials, int64_t count, double* out, hipStream_t st);
 // stats[0] = sum v^2, stats[1] = number of non-finite entries (as double)
 // mask (optional, domain decomposition): weights of the sums, 1 on the entries this rank owns and 0 elsewhere
-void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st, const double* mask = nullptr);
+// ints (optional): nints device flags copied behind the sums as doubles (stats[2 ..] / stats3[3 ..]): one read-back for all
+void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st, const double* mask = nullptr,
+                      const int32_t* ints = nullptr, int nints = 0);
 // stats3 = [sum v*v, count of non-finite v, g.v] in one pass (values identical to launch_vec_stats + launch_dot)
 void launch_dir_stats(const double* v, const double* g, int64_t n, double* scratch, double* stats3, hipStream_t st,
-                      const double* mask = nullptr);
+                      const double* mask = nullptr, const int32_t* ints = nullptr, int nints = 0);
 void launch_dot(const double* a, const double* b, int64_t n, double* scratch, double* out, hipStream_t st, const double* mask = nullptr);
 void launch_index_gather(const double* v, const int32_t* idx, int64_t cnt, double* out, hipStream_t st);     // out[i] = v[idx[i]]
 void launch_index_scatter(const double* in, const int32_t* idx, int64_t cnt, double* v, hipStream_t st);    // v[idx[i]] = in[i]

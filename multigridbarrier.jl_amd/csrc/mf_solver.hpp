@@ -60,6 +60,7 @@ class MfSolver {
     const LeafDesc* leaf_desc() const { return d_leaf_desc.p; }
     double* arena() { return d_arena.p; }
     int32_t* leaf_status() { return d_status.p + 1; }
+    const int32_t* status_flags() const { return d_status.p; }      // [0] factorization, [1] leaf pivots (device)
     // Second scatter list for the same plan: CSR position q -> value_map[q], border entry v -> tail_base + v.
     void set_direct_map(const int32_t* value_map, int64_t nnz, int64_t tail_base, hipStream_t st);
     bool has_direct_map() const { return d_a_src_direct.n > 0; }
