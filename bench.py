@@ -320,6 +320,9 @@ def main():
                                    f"amg(subdivide(fem2d_P2(), {args.L})), n={n} broken nodes, {main.level_sizes[fine]} fine unknowns",
                        "hierarchy": f"amg_ruge_stuben({used if used else 'max_coarse=2: the reference default'})",
                        "hierarchy_is_reference_default": not used,
+                       "hierarchy_note": ("the ladder comes from this package's restatement of AlgebraicMultigrid.jl's Ruge-Stueben "
+                                          "(the third-party package is not in the reference tree: P entries are parity-unpinned, "
+                                          "DESIGN.md section 1); the reference's tests pin only the downstream z"),
                        "levels": [int(v) for v in main.level_sizes],
                        "parallelism": "replicas" if world > 1 else "single",
                        "solver_controls": "reference defaults (tol=sqrt(eps), t=0.1, kappa=10, max_newton=8, backtracking)"},

@@ -180,11 +180,11 @@ class ShardedBarrier:
         """Global gradient: interior entries are already complete on their owner and zero elsewhere, so only
         the interface entries travel; every rank returns the full vector (s is replicated)."""
         g = np.asarray(self.local.f1(level, s, self.c_local(c), self.z_local(z0)), dtype=np.float64)
-        pl = self.plan(level)
         if self.world == 1:
             return g
-        # interface entries: summed; interior entries: exactly one rank holds a non-zero -> the same sum,
-        # sent as one buffer [interface | interior] so that every rank ends with the replicated gradient
+        # replicated result: the sum over ranks is a gather for interior entries (one rank holds a non-zero) and the
+        # interface sum for the others.  The interface-only form is `f1_interface_only`; the domain-decomposed solver
+        # below never replicates a gradient at all.
         return self._allreduce(g)
 
     def f1_interface_only(self, level: int, s, c, z0) -> Tuple[np.ndarray, np.ndarray]:

@@ -189,6 +189,121 @@ def _run_core(P, z, c, opt, what):
     return diag
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# A custom `line_search` closure (reference: src/mgb.jl:362, src/newton.jl:84-154) takes the objective closures
+# themselves, which the resident ramp cannot call back into: such solves run the reference's loops here, on DEVICE vectors
+# through the fine-grained entry points (mgbhip_f0_d / f1_d / f2_d / solve_d / prolong_add) --
+# nothing but scalars crosses PCIe.  The Julia extension does the same with the reference's own `newton`.
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _newton_on_device(F0, F1, F2solve, x, maxit, stop, line_search):
+    """src/newton.jl:227-287 on DeviceVectors; F2solve(x, g) returns the Newton direction H(x)^{-1} g."""
+    if not x.all_isfinite():
+        raise FloatingPointError("newton: initial point has non-finite entries")
+    y = F0(x)
+    if not math.isfinite(y):
+        raise FloatingPointError("newton: initial objective value is not finite")
+    ymin, g, k, converged = y, F1(x), 0, False
+    if not g.all_isfinite():
+        raise FloatingPointError("newton: initial gradient has non-finite entries")
+    gmin, incmin = g.norm(), math.inf
+    while k < maxit and not converged:
+        k += 1
+        n = F2solve(x, g)
+        if not n.all_isfinite():
+            raise FloatingPointError("newton: Newton direction has non-finite entries")
+        inc = g.dot(n)
+        if inc <= 0:
+            converged = abs(inc) <= EPS * max(abs(y), 1.0)
+            break
+        xn, yn, gn = line_search(x, y, g, n, F0, F1)
+        if stop(ymin, yn, gmin, gn, n, math.sqrt(incmin), math.sqrt(inc)):
+            converged = True
+        x, y, g = xn, yn, gn
+        gmin, ymin, incmin = min(gmin, g.norm()), min(ymin, y), min(inc, incmin)
+    return x, k, converged
+
+
+def _generic_core(P, z, c, opt, line_search, stopping_criterion=None, early_stop_fn=None):
+    """mgb_step + mgb_core (src/mgb.jl:16-183) around `_newton_on_device`.  Returns the diagnostics dict of `_run_core`."""
+    L = len(P.level_sizes)
+    n = P.n
+    sc = stopping_criterion
+    if sc is None:
+        lt, th = opt.stop_lambda_tol, opt.stop_theta
+        sc = lambda ymin, yn, gmin, gn, nn, ndmin, nd: (lt >= 0 and nd < lt) or (yn >= ymin and gn.norm() >= th * gmin)
+    fth = opt.finalize_theta
+    fin = (lambda ymin, yn, gmin, gn, nn, ndmin, nd: yn >= ymin and gn.norm() >= fth * gmin) if opt.finalize else None
+    zv = P.vec(np.asarray(z, dtype=np.float64))
+    t0 = time.time()
+
+    def step(cv, finalize_now, initial_step):
+        nonlocal zv
+        its = np.zeros(L, dtype=np.int64)
+        zsave = zv.copy()
+
+        def eta(j, J, crit, mi):
+            lev = J - 1
+            zJ = zv.copy()
+            F0 = lambda s: P.f0_d(lev, s, cv, zJ)
+            F1 = lambda s: P.f1_d(lev, s, cv, zJ)
+
+            def F2solve(s, g):
+                P.f2_d(lev, s, cv, zJ)
+                return P.solve_d(lev, g)
+            x, k, ok = _newton_on_device(F0, F1, F2solve, P.vec(length=P.level_sizes[lev]), mi, crit, line_search)
+            its[lev] += k
+            if ok:
+                P.prolong_add(lev, x, zv)
+            return ok
+
+        def dac(j, J):
+            if eta(j, J, sc, opt.maxit if (initial_step and J - j == 1) else opt.max_newton):
+                return True
+            mid = (j + J) // 2
+            if mid == j or mid == J:
+                return False
+            return dac(j, mid) and dac(mid, J)
+        ok = dac(0, L)
+        if finalize_now and fin is not None:
+            ok = eta(L - 1, L, fin, opt.maxit) and ok
+        if not ok:
+            zv = zsave                                   # z = SOL.z only on success (src/mgb.jl:150-157)
+        return its, ok
+
+    cflat = np.asfortranarray(c, dtype=np.float64).reshape(-1, order="F")
+    cvec = lambda tt: P.vec(tt * cflat)
+    tol, t, kappa, kappa0 = opt.tol, opt.t, opt.kappa, opt.kappa
+    target = 1.0 / tol
+    stop_early = (lambda zz, tt: False) if early_stop_fn is None else early_stop_fn
+    its_all, ts, kappas = [], [], []
+    its, ok = step(cvec(t), bool(opt.finalize) and t >= target, True)
+    if not ok:
+        raise MGBConvergenceFailure(f"Initial centering failed in mgb_solve at t={t}, tol={tol}, maxit={opt.maxit}.", "stall")
+    its_all.append(its); ts.append(t); kappas.append(kappa)
+    k = 1
+    while t < target and kappa > 1 and k < opt.maxit and not stop_early(zv.to_host(), t):
+        k += 1
+        acc = np.zeros(L, dtype=np.int64)
+        while kappa > 1:
+            t1 = kappa * t
+            its, ok = step(cvec(t1), bool(opt.finalize) and t1 >= target, False)
+            acc += its
+            if ok:
+                if its.max() <= opt.max_newton * 0.5:
+                    kappa = min(kappa0, kappa * kappa)
+                t = t1
+                break
+            kappa = math.sqrt(kappa)
+        its_all.append(acc); ts.append(t); kappas.append(kappa)
+    if not (t >= target or stop_early(zv.to_host(), t)):
+        raise MGBConvergenceFailure(f"Convergence failure in mgb_solve at t={t}, k={k}, kappa={kappa}, tol={tol}, maxit={opt.maxit}.",
+                                    "stall" if kappa <= 1 else "iteration_limit")
+    return dict(z=zv.to_host(), its=np.stack(its_all, axis=1), ts=np.array(ts), kappas=np.array(kappas), times=np.zeros(0),
+                c_dot_Dz=np.zeros(0), t_elapsed=time.time() - t0, t_final=t, solve_seconds=0.0,
+                newton_iterations=int(np.sum(its_all)), failure_code=0, k=k)
+
+
 def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[float] = None,
                feasibility_Rmax: float = 1.0 / math.sqrt(EPS), tol=None, kappa=None, maxit=None, max_newton=None,
                stopping_criterion=None, line_search=None, finalize=None, barrier_nodes="default",
@@ -234,7 +349,8 @@ def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[floa
             feas.set_box(float(b), Rbox)
             failure = None
             try:
-                opt = _options(feas, t=t_feasibility, early_stop=1, keep=keep, **common)
+                # (a callable line_search applies to the main phase; phase I runs the resident ramp with the default search)
+                opt = _options(feas, t=t_feasibility, early_stop=1, keep=keep, **(dict(common, line_search=None) if callable(line_search) else common))
                 SOL_feasibility = _run_core(feas, z1, c1, opt, "feasibility phase")
             except (MGBConvergenceFailure, dev.MGBHipError) as e2:   # each round is a probe (src/mgb.jl:505-515)
                 failure = e2
@@ -269,8 +385,17 @@ def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[floa
         printlog("_matched_t: starting main ramp at t=", tm)
         t = min(t, tm)
     main.set_barrier_weights(bw_main)
-    opt = _options(main, t=t, early_stop=0, early_stop_fn=early_stop, keep=keep, **common)
-    SOL_main = _run_core(main, z2, c0, opt, "main phase")
+    if callable(line_search):
+        # (x, y, g, n, F0, F1) -> (xnext, ynext, gnext) on device vectors: the generic loops of this module
+        common_g = dict(common, line_search=None, stopping_criterion=None if callable(stopping_criterion) else stopping_criterion)
+        opt = _options(main, t=t, early_stop=0, keep=keep, **common_g)
+        two = early_stop is not None and len(__import__("inspect").signature(early_stop).parameters) >= 2
+        es = None if early_stop is None else ((lambda zz, tt: bool(early_stop(zz, tt))) if two else (lambda zz, tt: bool(early_stop(zz))))
+        SOL_main = _generic_core(main, z2, c0, opt, line_search,
+                                 stopping_criterion=stopping_criterion if callable(stopping_criterion) else None, early_stop_fn=es)
+    else:
+        opt = _options(main, t=t, early_stop=0, early_stop_fn=early_stop, keep=keep, **common)
+        SOL_main = _run_core(main, z2, c0, opt, "main phase")
     z = SOL_main["z"].reshape(ncomp, m).T.copy()
     return dict(z=z, SOL_feasibility=SOL_feasibility, SOL_main=SOL_main)
 

@@ -643,6 +643,42 @@ def test_user_stopping_criterion_and_early_stop_callables():
     assert np.abs(sol_e.z - ref_e["z"]).max() < 1e-8 and s_of(stacked(sol_e.z)).max() < 8.0
 
 
+def test_custom_line_search_closure_runs_on_device_vectors():
+    """`line_search=` accepts any callable of the reference's form `(x, y, g, n, F0, F1) -> (xnext, ynext, gnext)`
+    (src/mgb.jl:362, src/newton.jl:139-154): the solve then runs the reference's loops on device vectors through the
+    fine-grained entry points.  A closure that restates linesearch_backtracking must
+    reproduce the resident ramp's solve."""
+    import math
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 3)), p=1.5)
+    calls = {"n": 0}
+
+    def my_backtracking(x, y, g, n, F0, F1, beta=0.5, c1=0.1):
+        calls["n"] += 1
+        inc = g.dot(n)
+        s = 1.0
+        xn, yn, gn = x, y, g
+        while s > 0.0:
+            xt = x - s * n
+            stalled = (xt - x).norm() == 0.0
+            yt = F0(xt)
+            if math.isfinite(yt):
+                gt = F1(xt)
+                if gt.all_isfinite():
+                    xn, yn, gn = xt, yt, gt
+                    if stalled or yt <= y - c1 * inc * s:
+                        break
+            s *= beta
+        return xn, yn, gn
+    base = m.mgb_solve(prob)
+    sol = m.mgb_solve(prob, line_search=my_backtracking)
+    assert calls["n"] > 50
+    assert np.abs(sol.z - base.z).max() < 1e-9
+    a, b = np.asarray(sol.SOL_main["its"]), np.asarray(base.SOL_main["its"])
+    assert a.shape == b.shape and np.abs(a - b).max() <= 1            # generic solve path (forward + backward sweeps) vs the bordered one
+    ref = O.mgb_solve(prob)
+    assert np.abs(sol.z - ref["z"]).max() < 1e-8
+
+
 # the nine CPU-vs-device cases of the reference's CUDA extension test (test/test_cuda.jl:34-56); fem2d_P1 is
 # outside this package's scope (SURVEY.md section 2: no hot-path role), the other eight run device vs oracle
 CUDA_EXT_CASES = {
