@@ -574,6 +574,7 @@ def test_c_dot_Dz_diagnostic_matches_oracle():
 #   L = 9, p = 1.5: in the 2-unknown space H (eigenvalues -1.3e2 .. 4.1e16) comes out indefinite after 28 iterations:
 #                   lambda^2 = -1.1e-3, "Initial centering failed" -- the algorithm's own limit in fp64.
 ORACLE_L8_LEVEL0 = (950, 1000)        # tests/dev/logs/oracle_fem2d_P2_L8_p1.5_default.log: converged between these k
+ORACLE_L8_PER_LEVEL = [988, 23, 10, 30, 0, 5, 0, 0, 139]      # same log, last line: CONVERGED, total 1195 (7588 s of NumPy)
 ORACLE_L9_FAIL_K = 28                 # tests/dev/logs/oracle_coarsest_newton_L9_p1.5.log
 
 
@@ -592,6 +593,9 @@ def test_default_hierarchy_p15_same_outcome_as_oracle_at_L8_and_L9():
     lo, hi = ORACLE_L8_LEVEL0
     assert 0.95 * lo <= its[0, 0] <= 1.05 * hi, its[:, 0]          # the creeping solve in the 4-unknown space
     assert its.sum() - its[0, 0] < 400                              # the rest of the solve is an ordinary one
+    per_level = its.sum(axis=1)
+    assert np.abs(per_level[1:] - np.array(ORACLE_L8_PER_LEVEL[1:])).max() <= 2, per_level    # every other space: the oracle's counts
+    assert abs(int(per_level[0]) - ORACLE_L8_PER_LEVEL[0]) <= 0.05 * ORACLE_L8_PER_LEVEL[0], per_level
     # L = 9: both stop in the coarsest space after a few dozen iterations
     prob9 = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 9)), p=1.5)
     assert [R.shape[1] for R in prob9.M[0].R_fine][:3] == [2, 7, 18]
