@@ -65,6 +65,15 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// Exchange of a double inside a quad of lanes on the data-parallel path (two v_mov_b32 dpp): quad_perm control
+// 0xB1 = lanes [1,0,3,2] (xor 1), 0x4E = [2,3,0,1] (xor 2).  __shfl_xor goes through ds_bpermute, i.e. the LDS pipeline.
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_f64(double v) {      // also row_ror:n (0x120 + n): rotation inside 16 lanes
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 
 // 1/d by v_rcp_f64 and two Newton steps (the pivot chain of the in-register LDL' is latency
 // bound; the full IEEE division sequence is twice as long).  Error < 1 ulp of the quotient, and
@@ -2072,12 +2081,18 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __res
 }
 
 // backward:  x_j = u_j - M_j G_j,  G[q] = sum over solved rows r of A[r, q] x[r]
+#ifdef MGB_STEP_PROBE      // root front of a sweep: phase timestamps (tools/gpu_probe_bwd.py)
+#define BP(i) do { if (threadIdx.x == 0 && gridDim.x == 1 && fr[first].k > 400) g_probe[(i)] = wall_clock64(); } while (0)
+#else
+#define BP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __restrict__ fr, int32_t first,
                                                            const int32_t* __restrict__ front_idx,
                                                            const double* __restrict__ arena,
                                                            const double* __restrict__ dvec,
                                                            const double* __restrict__ y, double* __restrict__ x) {
     extern __shared__ double sh[];
+    BP(0);
     const FrontDev F = fr[first + blockIdx.x];
     const int m = F.m, k = F.k;
     const int tid = threadIdx.x, nt = BIGI_THREADS;
@@ -2086,13 +2101,29 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __res
     double* gl = sh + ((m + 1) & ~1);              // [k]
     double* Ml = gl + ((k + 1) & ~1);              // [NB][NB + 1]
     double* zq = Ml + NB * (NB + 1);               // [NB]
+    int32_t* il = reinterpret_cast<int32_t*>(zq + 2 * NB);    // [m]: the front's index list (x_j is scattered through it)
     const int32_t* idx = front_idx + F.idx_off;
     const double* Fm = arena + F.F_off;
     const double* dv = dvec + F.idx_off;
-    for (int j = tid; j < m; j += nt) tl[j] = (j < k) ? y[idx[j]] : x[idx[j]];
+    for (int j = tid; j < m; j += nt) {
+        const int32_t ij = idx[j];
+        il[j] = ij;
+        tl[j] = (j < k) ? y[ij] : x[ij];
+    }
     __syncthreads();
+    BP(1);
     // boundary rows: one wave per pivot column, coalesced along rows; four columns per pass so that their loads
     // and butterflies overlap (a wave owns up to k / 16 columns, each a dependent load -> reduce chain)
+    // A front with a handful of boundary rows (the root: the border row alone) takes one thread per column instead: the
+    // butterflies of 511 columns for one row each kept the LDS pipeline of the workgroup busy for 17 us.
+    if (m - k <= 8) {
+        for (int q = tid; q < k; q += nt) {
+            const double* Aq = Fm + (int64_t)q * m;
+            double sq = 0.0;
+            for (int r = k; r < m; ++r) sq += Aq[r] * tl[r];
+            gl[q] = sq;
+        }
+    } else
     for (int q0 = 4 * wave; q0 < k; q0 += 4 * (nt / 64)) {
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         for (int r = k + lane; r < m; r += 64) {
@@ -2101,10 +2132,17 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __res
             for (int u = 0; u < 4; ++u) s[u] += Fm[(int64_t)min(q0 + u, k - 1) * m + r] * t;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            for (int off = 32; off > 0; off >>= 1) s[u] += __shfl_xor(s[u], off, 64);
+        for (int u = 0; u < 4; ++u) {           // rows of 16 lanes on the data-parallel path, the four rows through the crossbar
+            s[u] += quad_perm_f64<0xB1>(s[u]);
+            s[u] += quad_perm_f64<0x4E>(s[u]);
+            s[u] += quad_perm_f64<0x124>(s[u]);
+            s[u] += quad_perm_f64<0x128>(s[u]);
+            s[u] += __shfl_xor(s[u], 16, 64);
+            s[u] += __shfl_xor(s[u], 32, 64);
+        }
         if (lane < 4 && q0 + lane < k) gl[q0 + lane] = s[lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? 2 : 3))];
     }
+    BP(2);
     const int wa = tid % NB, wb = tid / NB;
     const int last = ((k - 1) / NB) * NB;
     {
@@ -2113,51 +2151,101 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_bwd_inv(const FrontDev* __res
         if (tid < NB) Ml[tid * (NB + 1) + tid] = (last + tid < k) ? dv[last + tid] : 0.0;
     }
     __syncthreads();
+    // Panel rows of a block step: G[q] += sum_u A[j0 + u, q] x[j0 + u] for every unsolved pivot column q < j0.  Column q
+    // holds its 32 entries contiguously (256 B), so FOUR lanes share a column: per load instruction they cover 64
+    // contiguous bytes (16-byte loads, 8-byte aligned) and a wave touches 16 cache lines instead of 64 -- one lane per
+    // column made the texture addresser the bottleneck (6 us per step on the 511-pivot root front).  The four partial
+    // sums meet in two butterfly steps, in a fixed order.
+    struct __attribute__((aligned(8))) D2 { double a, b; };
+    const int cq = tid >> 2, cp = tid & 3;           // column within a pass of nt / 4 columns, quarter of the column
+    constexpr int CPP = BIGI_THREADS / 4;
+    // The first two passes of a step's panel rows are requested at the top of the step and run under the block
+    // product.  A column's base address is formed once.
+    const double* col0 = Fm + (int64_t)min(cq, k - 1) * m + 2 * cp;
+    const double* col1 = Fm + (int64_t)min(cq + CPP, k - 1) * m + 2 * cp;
+    BP(3);
     for (int j0 = last; j0 >= 0; j0 -= NB) {
         const int nb = min(NB, k - j0);
         const int jn = j0 - NB;              // the next block is a full one
+        if (j0 == 256) BP(4);
+        if (j0 == 224) BP(8);
         const double wnext = (wa < wb && jn >= 0) ? Fm[(jn + wa) + (int64_t)(jn + wb) * m] : 0.0;
         const double dnext = (tid < NB && jn >= 0) ? dv[jn + tid] : 0.0;
-        double pa[NB];                       // this thread's panel row, in flight under the block product
-        {
-            const double* Aq = Fm + (int64_t)tid * m + j0;
+        D2 pa[2][4];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) pa[u] = (tid < j0) ? Aq[min(u, nb - 1)] : 0.0;
+        for (int ps = 0; ps < 2; ++ps) {
+            const double* Aq = (ps ? col1 : col0) + j0;
+            if (cq + ps * CPP < j0) {
+                if (nb == NB) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pa[ps][t] = *reinterpret_cast<const D2*>(Aq + 8 * t);
+                } else {             // only the first step of a sweep can be a partial block
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int o = 2 * cp + 8 * t;
+                        pa[ps][t].a = Aq[min(o, nb - 1) - 2 * cp];
+                        pa[ps][t].b = Aq[min(o + 1, nb - 1) - 2 * cp];
+                    }
+                }
+            }
         }
         {   // x_j = u_j - M_j G_j with all 1024 threads (see the forward sweep)
             const int q = tid >> 5, c = tid & 31;
             double ph = Ml[q * (NB + 1) + c] * (c < nb ? gl[j0 + c] : 0.0);
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) ph += __shfl_xor(ph, off, 32);
-            if (c == 0) {
-                const double xv = (q < nb) ? tl[j0 + q] - ph : 0.0;
-                zq[q] = xv;
-                if (q < nb) x[idx[j0 + q]] = xv;
-            }
+            ph += quad_perm_f64<0xB1>(ph);          // quads, then rotations by 4 and 8 inside the row of 16 lanes (DPP) ...
+            ph += quad_perm_f64<0x4E>(ph);
+            ph += quad_perm_f64<0x124>(ph);
+            ph += quad_perm_f64<0x128>(ph);
+            ph += __shfl_xor(ph, 16, 32);           // ... and one exchange between the two rows through the LDS crossbar
+            if (c == 0) zq[q] = (q < nb) ? tl[j0 + q] - ph : 0.0;
         }
+        if (j0 == 256) BP(5);
         __syncthreads();
+        if (j0 == 256) BP(6);
+        if (tid < nb) x[il[j0 + tid]] = zq[tid];
         if (wa < wb) { Ml[wb * (NB + 1) + wa] = wnext; Ml[wa * (NB + 1) + wb] = wnext; }
         if (tid < NB) Ml[tid * (NB + 1) + tid] = dnext;
-        if (tid < j0) {
-            double v = 0.0;
+        double zr[8];                        // this lane's eight entries of x_j (zero beyond nb)
 #pragma unroll
-            for (int u = 0; u < NB; ++u) v += pa[u] * zq[u];          // zq is zero beyond nb
-            gl[tid] += v;
+        for (int t = 0; t < 4; ++t) {
+            zr[2 * t] = zq[2 * cp + 8 * t];
+            zr[2 * t + 1] = zq[2 * cp + 8 * t + 1];
         }
-        for (int q = tid + nt; q < j0; q += nt) {
-            const double* Aq = Fm + (int64_t)q * m + j0;
-            double v = 0.0;
-            for (int c0 = 0; c0 < nb; c0 += 8) {                // eight loads in flight (see the forward sweep)
-                double a[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] = Aq[min(c0 + u, nb - 1)];
+        for (int ps = 0; ps < 2; ++ps) {
+            const int q = cq + ps * CPP;
+            if (q < j0) {                    // the four lanes of a column decide alike
+                double v = 0.0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v += a[u] * zq[c0 + u];
+                for (int t = 0; t < 4; ++t) v += pa[ps][t].a * zr[2 * t] + pa[ps][t].b * zr[2 * t + 1];
+                v += quad_perm_f64<0xB1>(v);
+                v += quad_perm_f64<0x4E>(v);
+                if (cp == 0) gl[q] += v;
             }
-            gl[q] += v;
         }
+        for (int q = cq + 2 * CPP; q - cq < j0; q += CPP) {          // fronts with more than 512 unsolved columns
+            const double* Aq = Fm + (int64_t)min(q, j0 - 1) * m + j0 + 2 * cp;
+            D2 a[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (nb == NB) a[t] = *reinterpret_cast<const D2*>(Aq + 8 * t);
+                else {
+                    const int o = 2 * cp + 8 * t;
+                    a[t].a = Aq[min(o, nb - 1) - 2 * cp];
+                    a[t].b = Aq[min(o + 1, nb - 1) - 2 * cp];
+                }
+            }
+            double v = 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v += a[t].a * zr[2 * t] + a[t].b * zr[2 * t + 1];
+            v += quad_perm_f64<0xB1>(v);
+            v += quad_perm_f64<0x4E>(v);
+            if (cp == 0 && q < j0) gl[q] += v;
+        }
+        if (j0 == 256) BP(7);
         __syncthreads();
     }
+    BP(9);
 }
 
 }  // namespace
@@ -2219,7 +2307,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     bool inv_ok = true;
     if (const char* e = getenv("MGBHIP_OLD_BIG"); e && e[0] == '1') inv_ok = false;
     if (inv_ok) {
-        const int lds = (2 * BIG_INV_MAX_M + NB * (NB + 1) + 4 * NB + 8 + BIGI_THREADS) * (int)sizeof(double);
+        const int lds = (2 * BIG_INV_MAX_M + BIG_INV_MAX_M / 2 + NB * (NB + 1) + 4 * NB + 8 + BIGI_THREADS) * (int)sizeof(double);    // 157 728 B of the 160 KB
         if (hipFuncSetAttribute((const void*)mf_fwd_inv, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
             hipFuncSetAttribute((const void*)mf_bwd_inv, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             (void)hipGetLastError();
@@ -2707,7 +2795,7 @@ void MfSolver::backward_pass(double* d_x, hipStream_t st, StageTimers* timers) {
                 hipLaunchKernelGGL(mf_backward_small, dim3((L.count + 3) / 4), dim3(256), 0, st, d_fronts.p, L.first,
                                    L.count, d_front_idx.p, d_arena.p, d_y.p, d_x);
             } else if (L.inv && factored_inv) {
-                const size_t lds = (size_t)(((L.max_m + 1) & ~1) + ((L.max_k + 1) & ~1) + NB * (NB + 1) + 2 * NB) * sizeof(double);
+                const size_t lds = (size_t)(((L.max_m + 1) & ~1) + ((L.max_k + 1) & ~1) + NB * (NB + 1) + 2 * NB + (L.max_m + 1) / 2) * sizeof(double);
                 hipLaunchKernelGGL(mf_bwd_inv, dim3(L.count), dim3(BIGI_THREADS), lds, st, d_fronts.p, L.first,
                                    d_front_idx.p, d_arena.p, d_dvec.p, d_y.p, d_x);
             } else if (L.max_m <= BIG1_MAX_M) {
