@@ -74,6 +74,21 @@ __device__ __forceinline__ double quad_perm_f64(double v) {      // also row_ror
     const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// Sum over a row of 16 lanes (every lane ends with it): no LDS traffic.
+__device__ __forceinline__ double row16_sum_f64(double v) {
+    v += quad_perm_f64<0xB1>(v);
+    v += quad_perm_f64<0x4E>(v);
+    v += quad_perm_f64<0x124>(v);
+    v += quad_perm_f64<0x128>(v);
+    return v;
+}
+// Sum over the wave: rows on the data-parallel path, the four rows through the crossbar (2 exchanges instead of 6).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v = row16_sum_f64(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
 
 // 1/d by v_rcp_f64 and two Newton steps (the pivot chain of the in-register LDL' is latency
 // bound; the full IEEE division sequence is twice as long).  Error < 1 ulp of the quotient, and
@@ -632,7 +647,7 @@ __global__ __launch_bounds__(256) void mf_backward_small(const FrontDev* __restr
         double s = 0.0;
         if (lane > j && lane < m) s += Lj[lane] * t0;
         if (r1 > j && r1 < m) s += Lj[r1] * t1;
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        s = wave_sum_f64(s);
         if (lane == j) t0 -= s;
         if (r1 == j) t1 -= s;
     }
@@ -1207,10 +1222,7 @@ __global__ __launch_bounds__(256) void mf_backward_tiny(const FrontDev* __restri
     for (int j = 15; j >= 0; --j) {
         if (j >= kmax) continue;
         double s = l[j] * t;                       // rows r > j of column j (zero elsewhere)
-        s += __shfl_xor(s, 8, 16);
-        s += __shfl_xor(s, 4, 16);
-        s += __shfl_xor(s, 2, 16);
-        s += __shfl_xor(s, 1, 16);
+        s = row16_sum_f64(s);
         if (r == j && j < k) t -= s;
     }
     if (row && r < k) x[myidx] = t;
