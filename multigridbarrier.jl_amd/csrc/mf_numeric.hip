@@ -420,17 +420,25 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
                                                       int32_t* __restrict__ status) {
     constexpr int PK = MW * (MW + 1) / 2;
     extern __shared__ double sh[];
+#ifdef MGB_STEP_PROBE      // one wave of the level-1 launch at L = 9: phase timestamps (tools/gpu_probe_wave.py)
+#define WP(i) do { if (threadIdx.x == 0 && gridDim.x == 2048 && blockIdx.x == 1500) g_probe[40 + (i)] = wall_clock64(); } while (0)
+#else
+#define WP(i) do { } while (0)
+#endif
+    WP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fi = blockIdx.x * 4 + wave;
     if (fi >= count) return;                       // waves are independent: no workgroup barrier below
     const FrontDev F = fr[first + fi];
     const int m = F.m, k = F.k;
     double* W = sh + (size_t)wave * PK;
-    // child descriptors of this wave (chunks of 64), behind the four fronts
-    int64_t* cU = reinterpret_cast<int64_t*>(sh + (size_t)4 * PK) + wave * 128;
-    int64_t* cR = cU + 64;
-    int32_t* cM = reinterpret_cast<int32_t*>(reinterpret_cast<int64_t*>(sh + (size_t)4 * PK) + 4 * 128) + wave * 128;
-    int32_t* cB = cM + 64;
+    // child descriptors of this wave (chunks of WCH), behind the four fronts: 4 x 48-row triangles + the descriptors
+    // stay under 40 KB, so four workgroups share a compute unit
+    constexpr int WCH = 32;
+    int64_t* cU = reinterpret_cast<int64_t*>(sh + (size_t)4 * PK) + wave * 2 * WCH;
+    int64_t* cR = cU + WCH;
+    int32_t* cM = reinterpret_cast<int32_t*>(reinterpret_cast<int64_t*>(sh + (size_t)4 * PK) + 4 * 2 * WCH) + wave * 2 * WCH;
+    int32_t* cB = cM + WCH;
     auto pidx = [](int r, int c) { return c * MW - c * (c - 1) / 2 + (r - c); };
     // first batch of A entries and the first chunk of child descriptors are requested before the triangle is zeroed
     int a_d0 = -1;
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
     }
     int64_t pU = 0, pR = 0;
     int32_t pM = 0, pB = 0;
-    if (lane < min(64, F.nchild)) {
+    if (lane < min(WCH, F.nchild)) {
         const FrontDev C = fr[children[F.child_off + lane]];
         child_update_desc(C, pU, pM);
         pR = C.rel_off;
@@ -449,11 +457,13 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
     }
     for (int i = lane; i < PK; i += 64) W[i] = 0.0;
     wave_sync();
+    WP(1);
     if (a_d0 >= 0) W[a_d0] = a_v0;
     for (int t = lane + 64; t < F.a_cnt; t += 64) W[a_dst[F.a_off + t]] = Hval[a_src[F.a_off + t]];
     wave_sync();
-    for (int cbase = 0; cbase < F.nchild; cbase += 64) {
-        const int nc = min(64, F.nchild - cbase);
+    WP(2);
+    for (int cbase = 0; cbase < F.nchild; cbase += WCH) {
+        const int nc = min(WCH, F.nchild - cbase);
         if (lane < nc) {
             if (cbase == 0) {
                 cU[lane] = pU; cR[lane] = pR; cM[lane] = pM; cB[lane] = pB;
@@ -468,22 +478,24 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
             }
         }
         wave_sync();
-        for (int c0 = 0; c0 < nc; c0 += 8) {
-            const int ng = min(8, nc - c0);
-            bool small8 = true;
-            for (int u = 0; u < ng; ++u) small8 = small8 && cB[c0 + u] * cB[c0 + u] <= 64;
-            if (small8) {
-                // eight small children: one entry per lane and child, all loads in flight, then added in child order
-                int dst[8];
-                double val[8];
+        for (int c0 = 0; c0 < nc; c0 += 16) {
+            const int ng = min(16, nc - c0);
+            bool small16 = true;
+            for (int u = 0; u < ng; ++u) small16 = small16 && cB[c0 + u] * cB[c0 + u] <= 64;
+            if (small16) {
+                // sixteen small children (the element leaves under a level-1 front): one entry per lane and child, all
+                // loads in flight at once, then added in child order.  j = lane / b by a float reciprocal: exact for
+                // lane < 64, b <= 8 ((lane + 1/2) / b stays 1/16 away from every integer).
+                int dst[16];
+                double val[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     dst[u] = -1;
                     val[u] = 0.0;
                     if (u < ng) {
                         const int c = c0 + u, b = cB[c];
                         if (lane < b * b) {
-                            const int j = lane / b, r = lane - j * b;
+                            const int j = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)b)), r = lane - j * b;
                             if (r >= j) {
                                 const int32_t* rl = rel + cR[c];
                                 dst[u] = pidx(rl[r], rl[j]);
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     if (u < ng) {
                         if (dst[u] >= 0) W[dst[u]] += val[u];
                         wave_sync();                    // child u's stores before child u+1's loads
@@ -529,10 +541,13 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
         }
         wave_sync();
     }
+    WP(3);
     double a[MW];
 #pragma unroll
     for (int c = 0; c < MW; ++c) a[c] = (lane < m && c <= lane) ? W[pidx(lane, c)] : 0.0;
+    WP(4);
     const bool bad = wave_ldlt_regs<MW>(a, k, lane);
+    WP(5);
     if (bad) atomicOr(status, 1);
     if (lane < m) {
         double* Fg = arena + F.F_off;
@@ -540,6 +555,7 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
         for (int c = 0; c < MW; ++c)
             if (c <= lane) Fg[lane + (int64_t)c * m] = a[c];
     }
+    WP(6);
 }
 
 // Triangular solves of small fronts: one wave per front (4 fronts per workgroup), the work
@@ -2630,11 +2646,11 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
             } else if (L.wave) {
                 const dim3 gw((L.count + 3) / 4);
                 if (L.cls <= 32) {
-                    const size_t lds = (size_t)4 * (32 * 33 / 2) * sizeof(double) + 4 * 128 * (sizeof(int64_t) + sizeof(int32_t));
+                    const size_t lds = (size_t)4 * (32 * 33 / 2) * sizeof(double) + 4 * 64 * (sizeof(int64_t) + sizeof(int32_t));
                     hipLaunchKernelGGL(mf_factor_wave<32>, gw, dim3(256), lds, st, cur_fr, L.first, L.count, d_children.p, d_rel.p,
                                        a_src_p, cur_adst, d_values, d_arena.p, d_status.p);
                 } else {
-                    const size_t lds = (size_t)4 * (48 * 49 / 2) * sizeof(double) + 4 * 128 * (sizeof(int64_t) + sizeof(int32_t));
+                    const size_t lds = (size_t)4 * (48 * 49 / 2) * sizeof(double) + 4 * 64 * (sizeof(int64_t) + sizeof(int32_t));
                     hipLaunchKernelGGL(mf_factor_wave<48>, gw, dim3(256), lds, st, cur_fr, L.first, L.count, d_children.p, d_rel.p,
                                        a_src_p, cur_adst, d_values, d_arena.p, d_status.p);
                 }
