@@ -34,11 +34,14 @@ namespace {
 
 #ifdef MGB_STEP_PROBE      // development probe build only (tools/gpu_probe.py)
 __device__ long long g_probe[64];
-#define SP(i) do { if (threadIdx.x == 0 && gridDim.x > 8000 && gridDim.x < 8400 && blockIdx.x == 4096) g_probe[40 + i] = wall_clock64(); } while (0)
+#define SPL(i) do { if (threadIdx.x == 0 && gridDim.x == 1024 && blockIdx.x == 700 && j0 == 0) g_probe[48 + i] = wall_clock64(); } while (0)
+#define SP(i) do { if (threadIdx.x == 0 && gridDim.x == 4096 && blockIdx.x == 3000) g_probe[40 + i] = wall_clock64(); if (threadIdx.x == 0 && gridDim.x == 1024 && blockIdx.x == 700) g_probe[24 + i] = wall_clock64(); } while (0)
 #else
+#define SPL(i) do { } while (0)
 #define SP(i) do { } while (0)
 #endif
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int TX = 16;    // row lanes of the 2-D thread maps
 constexpr int NB = 32;    // panel width of the large-front path
 constexpr int CT = 8;     // destination columns per workgroup in the large-front assembly (2 per wave)
@@ -322,6 +325,7 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
     bool bad = false;
     for (int j0 = 0; j0 < k; j0 += NBT) {
         const int nb = min(NBT, k - j0);
+        SPL(0);
         if (tid < 64) {                       // diagonal block in registers
             double a[NBT];
 #pragma unroll
@@ -334,7 +338,9 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                     if (c == tid) prinv[c] = 1.0 / a[c];      // pivot reciprocals for the row solves
                 }
         }
+        SPL(1);
         __syncthreads();
+        SPL(2);
         {                                     // panel rows: l = (a L11^{-T}) D^{-1}, one row per thread
             const int r = j0 + nb + tid;
             if (r < m) {
@@ -359,39 +365,44 @@ __global__ void mf_factor_small(const FrontDev* __restrict__ fr, int32_t first,
                 }
             }
         }
+        SPL(3);
         __syncthreads();
-        // rank-nb update of the trailing lower triangle, two columns x four rows per thread and
-        // pass: the eight multipliers of a row are read once for both columns, the scaled ones
-        // S(q, c) = l(c, q) d_q come straight from the row solve above
-        const int c0 = j0 + nb;
-        for (int c = c0 + ty; c < m; c += 2 * TYn) {
-            const int c2 = c + TYn;
-            const bool two = c2 < m;
-            double s1[NBT], s2[NBT];
+        SPL(4);
+        // rank-nb update of the trailing lower triangle on the matrix cores, one 16 x 16 tile per wave and pass:
+        //   W[r, c] -= sum_q l(r, q) * S(q, c),   S(q, c) = l(c, q) d_q from the row solve above.
+        // v_mfma_f64_16x16x4: lane (fr16, fk) feeds A[m = fr16][k = fk] = S(q, cc0 + fr16) and B[k = fk][n = fr16] =
+        // l(r0 + fr16, q), and holds D[m = fk + 4 i][n = fr16], i = 0..3 -- rows run along the 16 lanes, so every
+        // LDS access of a tile is 16 consecutive doubles.  The scalar form read 16 LDS operands per 2 FMAs and kept
+        // the LDS pipeline of the compute unit saturated (three fronts per unit: 17 us for a rank-15 update of 65 rows).
+        {
+            const int c0 = j0 + nb;
+            const int T = (m - c0 + 15) >> 4;
+            const int lane = tid & 63, fr16 = lane & 15, fk = lane >> 4;
+            for (int tile = tid >> 6; tile < T * (T + 1) / 2; tile += nt >> 6) {
+                int I = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+                while ((I + 1) * (I + 2) / 2 <= tile) ++I;
+                while (I * (I + 1) / 2 > tile) --I;
+                const int J = tile - I * (I + 1) / 2;
+                const int r0 = c0 + 16 * I, cc0 = c0 + 16 * J;
+                const int rr = min(r0 + fr16, m - 1), cc = min(cc0 + fr16, m - 1);       // tiles overhang the front: clamp, never stored
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < NBT; ++q) {
-                s1[q] = S[q * m + c];
-                s2[q] = two ? S[q * m + c2] : 0.0;
-            }
-            for (int r = c + tx; r < m; r += 4 * TX) {
+                for (int kk = 0; kk < NBT / 4; ++kk) {
+                    const int q = 4 * kk + fk;
+                    const double sa = S[q * m + cc];                                   // rows q >= nb of S are zero
+                    const double lb = (q < nb) ? W[rr + co(j0 + q)] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, lb, acc, 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int ri = r + i * TX;
-                    if (ri < m) {
-                        double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-                        for (int q = 0; q < NBT; ++q) {
-                            const double l = (q < nb) ? W[ri + co(j0 + q)] : 0.0;
-                            a1 += l * s1[q];
-                            a2 += l * s2[q];
-                        }
-                        W[ri + co(c)] -= a1;
-                        if (two && ri >= c2) W[ri + co(c2)] -= a2;
-                    }
+                    const int col = cc0 + fk + 4 * i, row = r0 + fr16;
+                    if (row < m && col < m && row >= col) W[row + co(col)] -= acc[i];
                 }
             }
         }
+        SPL(5);
         __syncthreads();
+        SPL(6);
     }
     SP(3);
     if (bad && tid == 0) atomicOr(status, 1);
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(256) void mf_factor_wave(const FrontDev* __restrict
     constexpr int PK = MW * (MW + 1) / 2;
     extern __shared__ double sh[];
 #ifdef MGB_STEP_PROBE      // one wave of the level-1 launch at L = 9: phase timestamps (tools/gpu_probe_wave.py)
-#define WP(i) do { if (threadIdx.x == 0 && gridDim.x == 2048 && blockIdx.x == 1500) g_probe[40 + (i)] = wall_clock64(); } while (0)
+#define WP(i) do { if (threadIdx.x == 0 && gridDim.x == 2048 && blockIdx.x == 1500) g_probe[8 + (i)] = wall_clock64(); } while (0)
 #else
 #define WP(i) do { } while (0)
 #endif
@@ -1399,7 +1410,6 @@ __global__ __launch_bounds__(BIG1_THREADS) void mf_bwd_big1(const FrontDev* __re
 constexpr int BIG_INV_MAX_M = 7000;     // work vectors of the single-workgroup solves stay in LDS
 constexpr int BIGI_THREADS = 1024;
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // Blocked LDL' of the 32 x 32 block in Dn (row-major lower triangle, in LDS) by the whole workgroup.
 // Every cross-thread hand-off on this chip costs several hundred cycles (measured: ~600 cycles per
