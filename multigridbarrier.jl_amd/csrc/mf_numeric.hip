@@ -652,6 +652,10 @@ __global__ __launch_bounds__(256) void mf_forward_small(const FrontDev* __restri
     }
 }
 
+// KMAX > 0: every front of the launch has k <= KMAX pivots and the lane's entries of all pivot columns are requested
+// before the first elimination step (the steps are a dependent chain; with the loads inside it every step paid a
+// memory latency).  KMAX == 0: the rolled form.
+template <int KMAX>
 __global__ __launch_bounds__(256) void mf_backward_small(const FrontDev* __restrict__ fr, int32_t first,
                                                          int32_t count,
                                                          const int32_t* __restrict__ front_idx,
@@ -666,17 +670,38 @@ __global__ __launch_bounds__(256) void mf_backward_small(const FrontDev* __restr
     const double* Fm = arena + F.F_off;
     const int r1 = lane + 64;
     double t0 = 0.0, t1 = 0.0;
-    if (lane < m) t0 = (lane < k) ? y[idx[lane]] : x[idx[lane]];
-    if (r1 < m) t1 = (r1 < k) ? y[idx[r1]] : x[idx[r1]];
+    if constexpr (KMAX > 0) {
+        double l0[KMAX], l1[KMAX];
+        const bool two = m > 64;                     // wave-uniform
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            l0[j] = (j < k && lane > j && lane < m) ? Fm[(int64_t)j * m + lane] : 0.0;
+            l1[j] = (two && j < k && r1 < m) ? Fm[(int64_t)j * m + r1] : 0.0;        // r1 > j always (k <= KMAX <= 64)
+        }
+        if (lane < m) t0 = (lane < k) ? y[idx[lane]] : x[idx[lane]];
+        if (r1 < m) t1 = (r1 < k) ? y[idx[r1]] : x[idx[r1]];
+#pragma unroll
+        for (int j = KMAX - 1; j >= 0; --j) {
+            if (j < k) {
+                double s = l0[j] * t0;
+                if (two) s += l1[j] * t1;
+                s = wave_sum_f64(s);
+                if (lane == j) t0 -= s;
+            }
+        }
+    } else {
+        if (lane < m) t0 = (lane < k) ? y[idx[lane]] : x[idx[lane]];
+        if (r1 < m) t1 = (r1 < k) ? y[idx[r1]] : x[idx[r1]];
 #pragma unroll 2
-    for (int j = k - 1; j >= 0; --j) {
-        const double* Lj = Fm + (int64_t)j * m;
-        double s = 0.0;
-        if (lane > j && lane < m) s += Lj[lane] * t0;
-        if (r1 > j && r1 < m) s += Lj[r1] * t1;
-        s = wave_sum_f64(s);
-        if (lane == j) t0 -= s;
-        if (r1 == j) t1 -= s;
+        for (int j = k - 1; j >= 0; --j) {
+            const double* Lj = Fm + (int64_t)j * m;
+            double s = 0.0;
+            if (lane > j && lane < m) s += Lj[lane] * t0;
+            if (r1 > j && r1 < m) s += Lj[r1] * t1;
+            s = wave_sum_f64(s);
+            if (lane == j) t0 -= s;
+            if (r1 == j) t1 -= s;
+        }
     }
     if (lane < k) x[idx[lane]] = t0;
     if (r1 < k) x[idx[r1]] = t1;
@@ -2830,8 +2855,14 @@ void MfSolver::backward_pass(double* d_x, hipStream_t st, StageTimers* timers) {
                 hipLaunchKernelGGL(mf_backward_tiny, dim3((L.count + 15) / 16), dim3(256), 0, st, d_fronts.p, L.first,
                                    L.count, d_front_idx.p, d_arena.p, d_y.p, d_x);
             } else if (L.cls) {
-                hipLaunchKernelGGL(mf_backward_small, dim3((L.count + 3) / 4), dim3(256), 0, st, d_fronts.p, L.first,
-                                   L.count, d_front_idx.p, d_arena.p, d_y.p, d_x);
+#define MGB_LAUNCH_BWD_SMALL(KM)                                                                                          \
+    hipLaunchKernelGGL(mf_backward_small<KM>, dim3((L.count + 3) / 4), dim3(256), 0, st, d_fronts.p, L.first, L.count, \
+                       d_front_idx.p, d_arena.p, d_y.p, d_x)
+                // (a 32-column variant holds 143 registers and loses more to occupancy on the 8192-front level than it gains)
+                if (L.max_k <= 8) MGB_LAUNCH_BWD_SMALL(8);
+                else if (L.max_k <= 16) MGB_LAUNCH_BWD_SMALL(16);
+                else MGB_LAUNCH_BWD_SMALL(0);
+#undef MGB_LAUNCH_BWD_SMALL
             } else if (L.inv && factored_inv) {
                 const size_t lds = (size_t)(((L.max_m + 1) & ~1) + ((L.max_k + 1) & ~1) + NB * (NB + 1) + 2 * NB + (L.max_m + 1) / 2) * sizeof(double);
                 hipLaunchKernelGGL(mf_bwd_inv, dim3(L.count), dim3(BIGI_THREADS), lds, st, d_fronts.p, L.first,
