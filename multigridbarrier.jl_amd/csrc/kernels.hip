@@ -22,6 +22,32 @@ namespace mgbhip {
 
 namespace {
 
+// Sum of one double per thread over a 256-thread workgroup, result in thread 0: rows of 16 lanes on the data-parallel
+// path (v_mov dpp: quad_perm 0xB1 / 0x4E, row_ror 4 / 8), the four rows of a wave through the crossbar, the four waves
+// through LDS -- one barrier instead of the eight of an LDS tree (the tail of every element-kernel workgroup).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_mov_f64<0xB1>(v);
+    v += dpp_mov_f64<0x4E>(v);
+    v += dpp_mov_f64<0x124>(v);
+    v += dpp_mov_f64<0x128>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ double block_sum_256(double v, double* scratch4) {      // scratch4: 4 doubles of LDS, free to use
+    v = wave_sum_dpp(v);
+    if ((threadIdx.x & 63) == 0) scratch4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (scratch4[0] + scratch4[1]) + (scratch4[2] + scratch4[3]);
+}
+
 __device__ __forceinline__ int tri_index(int k, int k2, int NY) {   // k <= k2
     return k * NY - (k * (k - 1)) / 2 + (k2 - k);
 }
@@ -118,13 +144,8 @@ __global__ __launch_bounds__(256) void elem_kernel(const ElemParams P, const int
             val = bar + P.w[node] * lin;
         }
         __syncthreads();            // zl / opL no longer needed: reuse LDS for the reduction
-        sh[tid] = val;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) sh[tid] += sh[tid + off];
-            __syncthreads();
-        }
-        if (tid == 0) P.out_partial[blockIdx.x] = sh[0];
+        const double tot = block_sum_256(val, sh);
+        if (tid == 0) P.out_partial[blockIdx.x] = tot;
         return;
     }
     if (MODE == MODE_NODE_SLACK) {
@@ -171,13 +192,8 @@ __global__ __launch_bounds__(256) void elem_kernel(const ElemParams P, const int
             }
         }
         __syncthreads();            // zl / opL / YL no longer needed: reuse LDS for the reduction
-        sh[tid] = val;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) sh[tid] += sh[tid + off];
-            __syncthreads();
-        }
-        if (tid == 0) P.out_partial[blockIdx.x] = sh[0];
+        const double tot = block_sum_256(val, sh);
+        if (tid == 0) P.out_partial[blockIdx.x] = tot;
         return;
     }
     if (MODE == MODE_F1) {
@@ -702,13 +718,8 @@ __global__ __launch_bounds__(256) void elem_f01_fast(const ElemParams Pm) {
         }
     }
     __syncthreads();            // operators / Y no longer needed: reuse LDS for the reduction
-    sh[tid] = val;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) sh[tid] += sh[tid + off];
-        __syncthreads();
-    }
-    if (tid == 0) Pm.out_partial[blockIdx.x] = sh[0];
+    const double tot = block_sum_256(val, sh);
+    if (tid == 0) Pm.out_partial[blockIdx.x] = tot;
 }
 
 // ---- compensated sums --------------------------------------------------------------------------
