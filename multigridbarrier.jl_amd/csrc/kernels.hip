@@ -32,6 +32,16 @@ __device__ __forceinline__ double dpp_mov_f64(double v) {
     const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// z0 + R s at row i.  Selection levels: the same arithmetic as prolong_kernel with a unit entry (v = z0; v += 1 * s[col]).
+__device__ __forceinline__ double z_at(const ElemParams& P, int64_t i) {
+    double v = P.z0[i];
+    if (P.zsel) {
+        const int32_t c = P.zsel[i];
+        if (c >= 0) v += P.zs[c];
+        if (P.zout) P.zout[i] = v;
+    }
+    return v;
+}
 __device__ __forceinline__ double wave_sum_dpp(double v) {
     v += dpp_mov_f64<0xB1>(v);
     v += dpp_mov_f64<0x4E>(v);
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(256) void elem_kernel(const ElemParams P, const int
     }
     // 2. fine broken-basis values of this element: z0 + R*s  (src/convex.jl:156)
     if (active) {
-        for (int a = 0; a < nu; ++a) zl[(el * nu + a) * G + r] = P.z0[(int64_t)a * n + node];
+        for (int a = 0; a < nu; ++a) zl[(el * nu + a) * G + r] = z_at(P, (int64_t)a * n + node);
     }
     __syncthreads();
 
@@ -337,6 +347,10 @@ __global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
     double* opL = zl + 256 * nu;                        // [nstage][EPB][PP]
     double* YL = opL + (size_t)Pm.nstage * EPB * PP;    // [EPB][NT][G]
 
+    // z0 + R s of this lane's node: requested first (selection levels chain two loads: column, then s)
+    double zr[MGBHIP_MAX_NU];
+#pragma unroll
+    for (int a = 0; a < MGBHIP_MAX_NU; ++a) zr[a] = (active && a < nu) ? z_at(Pm, (int64_t)a * n + node) : 0.0;
     {   // operator blocks of this workgroup's elements -> LDS.  All loads of a stage are issued before the first
         // LDS store (a rolled copy loop waits one memory latency per iteration)
         int64_t lim = (Pm.N - e0) * PP;
@@ -359,7 +373,9 @@ __global__ __launch_bounds__(256) void elem_f2_fast(const ElemParams Pm) {
         }
     }
     if (active) {
-        for (int a = 0; a < nu; ++a) zl[(el * nu + a) * G + r] = Pm.z0[(int64_t)a * n + node];
+#pragma unroll
+        for (int a = 0; a < MGBHIP_MAX_NU; ++a)
+            if (a < nu) zl[(el * nu + a) * G + r] = zr[a];
     }
     __syncthreads();
     const double* opE = opL + (size_t)el * PP;           // + slot * EPB * PP
@@ -660,7 +676,7 @@ __global__ __launch_bounds__(256) void elem_f01_fast(const ElemParams Pm) {
     double ck[NY];
     double wv = 0.0, bwv = 0.0;
     if (active) {
-        for (int a = 0; a < nu; ++a) zl[(el * nu + a) * G + r] = Pm.z0[(int64_t)a * n + node];
+        for (int a = 0; a < nu; ++a) zl[(el * nu + a) * G + r] = z_at(Pm, (int64_t)a * n + node);
 #pragma unroll
         for (int k = 0; k < NY; ++k) ck[k] = Pm.c[node + n * k];
         wv = Pm.w[node];

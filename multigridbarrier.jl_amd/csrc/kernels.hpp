@@ -46,6 +46,11 @@ struct ElemParams {
     int64_t leaf_slack0;                     // column of the slack unknown of broken node 0 (slack of node i = leaf_slack0 + i)
     int32_t* leaf_status;                    // |= 1 on a zero / non-finite pivot
     int32_t leaf_packed;                     // leaf fronts are packed lower triangles (FrontDev::packed)
+    // selection levels (every row of R has at most one entry, equal to 1): z = z0 + R s is formed inside the element
+    // kernels -- zsel[i] is the column of row i or -1, zs the level's unknown vector -- instead of by a prolongation launch
+    const int32_t* zsel;
+    const double* zs;
+    double* zout;                            // with zsel: the kernel also stores z0 + R s (the next evaluation at this point reads it)
 };
 
 // Fine-level Newton systems: H of the default problem couples the p broken slack unknowns of an element (diagonal

@@ -59,6 +59,17 @@ static void upload_csr(const mgbhip_csr& R, Level& L, hipStream_t st) {
     int32_t maxr = 0;
     for (int64_t i = 0; i < R.rows; ++i) maxr = std::max(maxr, L.hRptr[i + 1] - L.hRptr[i]);
     L.R_long = maxr > 64;
+    {   // selection rows: the element kernels read s through the column map and no prolongation kernel runs
+        bool unit = maxr <= 1 && getenv("MGBHIP_NO_FUSED_PROLONG") == nullptr;
+        for (int64_t q = 0; q < nnz && unit; ++q) unit = L.hRval[q] == 1.0;
+        L.R_unit = unit;
+        if (unit) {
+            std::vector<int32_t> sel((size_t)std::max<int64_t>(R.rows, 1), -1);
+            for (int64_t i = 0; i < R.rows; ++i)
+                if (L.hRptr[i + 1] > L.hRptr[i]) sel[(size_t)i] = L.hRcol[L.hRptr[i]];
+            L.Rsel.upload(sel, st);
+        }
+    }
     L.Tptr.upload(tp, st);
     L.Tcol.upload(tc.data(), tc.size(), st);
     L.Tval.upload(tv.data(), tv.size(), st);
@@ -639,6 +650,14 @@ ElemParams mgbhip_problem::base_params(int level, const double* d_s, const doubl
         const Level& L = levels[level];
         if (zf_stamp == zstamp && zf_level == level && zf_s == d_s && zf_z == d_zz) {
             // same evaluation point as the previous call: d_zfull is still valid
+        } else if (L.R_unit) {
+            // selection level: the element kernel gathers s itself and leaves z0 + R s in d_zfull for the next evaluation
+            // at this point (the Hessian at an accepted line-search trial reads it back instead of chaining two gathers)
+            E.zsel = L.Rsel.p;
+            E.zs = d_s;
+            E.zout = d_zfull.p;
+            zf_stamp = zstamp; zf_level = level; zf_s = d_s; zf_z = d_zz;
+            goto prolonged;
         } else if (L.R_long) {      // dense prolongation rows: wave per row
             MGB_HIP_CHECK(hipMemcpyAsync(d_zfull.p, d_zz, sizeof(double) * (size_t)L.rows, hipMemcpyDeviceToDevice, stream()));
             launch_csr_matvec(L.rows, L.Rptr.p, L.Rcol.p, L.Rval.p, d_s, d_zfull.p, true, true, stream());
@@ -648,6 +667,7 @@ ElemParams mgbhip_problem::base_params(int level, const double* d_s, const doubl
         zf_stamp = zstamp; zf_level = level; zf_s = d_s; zf_z = d_zz;
         E.z0 = d_zfull.p;
     }
+prolonged:
     E.bw = has_bw ? bw.p : nullptr;
     E.invn = 1.0 / (double)n;
     E.cone = cone;
@@ -811,6 +831,7 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
             cnt.f2++;
             return;
         }
+        zf_stamp = -1;              // nothing ran: base_params may have promised d_zfull to a kernel that was not launched
     }
     L.H_condensed = false;
     {

@@ -40,6 +40,8 @@ struct Level {
     DevBuf<int32_t> Rptr, Rcol, Tptr, Tcol;
     DevBuf<double> Rval, Tval;
     bool T_long = false, R_long = false;
+    bool R_unit = false;                  // every row of R: at most one entry, equal to 1 -> the element kernels prolong (Rsel)
+    DevBuf<int32_t> Rsel;
     int32_t T_chunks = 0;                 // > 0: rows of R' are long enough for the chunked matvec
     // assembly plan for H = R' H_blk R (reference: BlockAssemblyPlan, src/BlockMatrices.jl:281-491)
     bool planned = false;
