@@ -1,0 +1,114 @@
+// 32 x 32 LDL' of a diagonal block on ONE wave with the trailing updates on the fp64 matrix cores.
+// Included by mf_numeric.hip (inside its namespace, after fast_recip / readlane_f64) and by tools/micro/ldlt32_mfma_test.hip.
+#pragma once
+
+struct Blk4 { double w10, w20, w21, w30, w31, w32, i0, i1, i2, i3, d0, d1, d2, d3; };
+
+__device__ __forceinline__ bool ldlt4_serial(double a00, double a10, double a11, double a20, double a21, double a22, double a30,
+                                             double a31, double a32, double a33, Blk4& B, double (&l)[6]) {
+    const double d0 = a00, i0 = fast_recip(d0);
+    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    const double d1 = a11 - l10 * a10, i1 = fast_recip(d1);
+    const double t21 = a21 - l20 * a10, t31 = a31 - l30 * a10;
+    const double l21 = t21 * i1, l31 = t31 * i1;
+    const double d2 = a22 - l20 * a20 - l21 * t21, i2 = fast_recip(d2);
+    const double t32 = a32 - l30 * a20 - l31 * t21;
+    const double l32 = t32 * i2;
+    const double d3 = a33 - l30 * a30 - l31 * t31 - l32 * t32, i3 = fast_recip(d3);
+    B.d0 = d0; B.d1 = d1; B.d2 = d2; B.d3 = d3;
+    B.i0 = i0; B.i1 = i1; B.i2 = i2; B.i3 = i3;
+    B.w10 = -l10; B.w21 = -l21; B.w32 = -l32;
+    B.w20 = l21 * l10 - l20;
+    B.w31 = l32 * l21 - l31;
+    B.w30 = l31 * l10 + l32 * (l20 - l21 * l10) - l30;
+    l[0] = l10; l[1] = l20; l[2] = l21; l[3] = l30; l[4] = l31; l[5] = l32;
+    const double dmin = fmin(fmin(fabs(d0), fabs(d1)), fmin(fabs(d2), fabs(d3)));
+    return !(dmin > 0.0) || !isfinite(d0) || !isfinite(d1) || !isfinite(d2) || !isfinite(d3);
+}
+
+
+// The lower triangle lives in three 16 x 16 accumulator tiles of v_mfma_f64_16x16x4 (c00: rows/cols 0-15, c10: rows 16-31 x
+// cols 0-15, c11: rows/cols 16-31): lane (fr = lane & 15, fk = lane >> 4) holds entry (row fr, col 4 i + fk) of a tile in
+// register i -- so the FOUR columns of block step b (i = b & 3) already sit in the operand layout of the instruction
+// (operand index k = fk), and a step is: ten diagonal-block entries by v_readlane -> the 4 x 4 LDL' redundantly in every
+// lane -> the row's four entries through the crossbar -> s = a W4', l = s D^-1 -> C -= S L' as one MFMA per tile.  No LDS
+// round trip, no workgroup barrier inside the 32 columns (the 4 x 4-blocked workgroup version needed two per four columns:
+// 1 900 cycles per step, 6.4 us per block).
+// Contract (same as block_ldlt32_b4): Dn holds the lower triangle incl. diagonal of the nb x nb block, row-major, zeros above
+// the diagonal and beyond nb; on return the strictly lower unit factor (zeros elsewhere), dq the pivots (1 beyond nb).
+// Every thread of the 256-thread workgroup must call this.
+typedef double ld_double4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void block_ldlt32_mfma(double (*Dn)[32 + 1], double* dq, int nb, int tid, int32_t* __restrict__ status) {
+    constexpr int N32 = 32;
+    if (tid < N32 && tid >= nb) Dn[tid][tid] = 1.0;      // identity padding keeps the recurrences free of special cases
+    __syncthreads();
+    if (tid < 64) {
+        const int fr = tid & 15, fk = tid >> 4;
+        ld_double4_t c00, c10, c11;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            c00[i] = Dn[fr][4 * i + fk];
+            c10[i] = Dn[16 + fr][4 * i + fk];
+            c11[i] = Dn[16 + fr][16 + 4 * i + fk];
+        }
+        bool bad = false;
+#pragma unroll
+        for (int b = 0; b < N32 / 4; ++b) {
+            const int T = b >> 2, i = b & 3, cb = 4 * b, cn = cb + 4;
+            const double src = T == 0 ? c00[i] : c11[i];
+            const int l0 = 4 * i;                        // lane of entry (cb, cb); (cb + rr, cb + cc) is lane l0 + rr + 16 cc
+            const double a00 = readlane_f64(src, l0);
+            const double a10 = readlane_f64(src, l0 + 1), a11 = readlane_f64(src, l0 + 1 + 16);
+            const double a20 = readlane_f64(src, l0 + 2), a21 = readlane_f64(src, l0 + 2 + 16), a22 = readlane_f64(src, l0 + 2 + 32);
+            const double a30 = readlane_f64(src, l0 + 3), a31 = readlane_f64(src, l0 + 3 + 16), a32 = readlane_f64(src, l0 + 3 + 32),
+                         a33 = readlane_f64(src, l0 + 3 + 48);
+            Blk4 B;
+            double l[6];
+            bad |= ldlt4_serial(a00, a10, a11, a20, a21, a22, a30, a31, a32, a33, B, l);
+            if (tid == 0) {
+                dq[cb] = B.d0; dq[cb + 1] = B.d1; dq[cb + 2] = B.d2; dq[cb + 3] = B.d3;
+                Dn[cb + 1][cb] = l[0]; Dn[cb + 2][cb] = l[1]; Dn[cb + 2][cb + 1] = l[2];
+                Dn[cb + 3][cb] = l[3]; Dn[cb + 3][cb + 1] = l[4]; Dn[cb + 3][cb + 2] = l[5];
+            }
+            // panel rows of one tile row: x = this lane's entry (row, cb + fk); returns the operands s(row)[fk], l(row)[fk].
+            // (s = a W4' as one more MFMA with W4 padded into the A operand lands in the right lanes too, but its latency
+            // on the dependent path is longer than the four crossbar exchanges: 11.7k against 11.2k cycles per block.)
+            auto panel = [&](double x, int rowbase, double& ms, double& ml) {
+                const double a0 = __shfl(x, fr, 64), a1 = __shfl(x, fr + 16, 64), a2 = __shfl(x, fr + 32, 64),
+                             a3 = __shfl(x, fr + 48, 64);
+                const double s0 = a0;
+                const double s1 = a1 + a0 * B.w10;
+                const double s2 = a2 + a0 * B.w20 + a1 * B.w21;
+                const double s3 = a3 + a0 * B.w30 + a1 * B.w31 + a2 * B.w32;
+                const double sv = fk == 0 ? s0 : (fk == 1 ? s1 : (fk == 2 ? s2 : s3));
+                const double iv = fk == 0 ? B.i0 : (fk == 1 ? B.i1 : (fk == 2 ? B.i2 : B.i3));
+                const double lv = sv * iv;
+                const int row = rowbase + fr;
+                const bool valid = row >= cn;             // rows above the block are finished, rows inside it come from the 4 x 4
+                ms = valid ? sv : 0.0;
+                ml = valid ? lv : 0.0;
+                if (valid) Dn[row][cb + fk] = lv;
+            };
+            if (T == 0) {
+                double sA, lA, sB, lB;
+                panel(c00[i], 0, sA, lA);
+                panel(c10[i], 16, sB, lB);
+                if (cn < 16) c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lA, -sA, c00, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(lA, -sB, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(lB, -sB, c11, 0, 0, 0);
+            } else if (cn < N32) {
+                double sB, lB;
+                panel(c11[i], 16, sB, lB);
+                c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(lB, -sB, c11, 0, 0, 0);
+            }
+        }
+        if (bad && status && tid == 0) atomicOr(status, 1);
+    }
+    __syncthreads();
+    // strictly lower L only: clear the diagonal and everything above it
+    for (int i = tid; i < N32 * N32; i += 256) {
+        const int rr = i / N32, cc = i % N32;
+        if (cc >= rr || rr >= nb) Dn[rr][cc] = 0.0;
+    }
+    __syncthreads();
+}

@@ -1446,29 +1446,7 @@ constexpr int BIGI_THREADS = 1024;
 //            ten lanes of wave 0, and lane 0 factors it at once while the other waves finish the update
 // -> two workgroup barriers per four columns.  On return Dn holds the strictly lower unit factor (zeros
 // elsewhere, identity beyond nb), dq the pivots (1 beyond nb).  Every thread of the workgroup must call this.
-struct Blk4 { double w10, w20, w21, w30, w31, w32, i0, i1, i2, i3, d0, d1, d2, d3; };
-
-__device__ __forceinline__ bool ldlt4_serial(double a00, double a10, double a11, double a20, double a21, double a22, double a30,
-                                             double a31, double a32, double a33, Blk4& B, double (&l)[6]) {
-    const double d0 = a00, i0 = fast_recip(d0);
-    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-    const double d1 = a11 - l10 * a10, i1 = fast_recip(d1);
-    const double t21 = a21 - l20 * a10, t31 = a31 - l30 * a10;
-    const double l21 = t21 * i1, l31 = t31 * i1;
-    const double d2 = a22 - l20 * a20 - l21 * t21, i2 = fast_recip(d2);
-    const double t32 = a32 - l30 * a20 - l31 * t21;
-    const double l32 = t32 * i2;
-    const double d3 = a33 - l30 * a30 - l31 * t31 - l32 * t32, i3 = fast_recip(d3);
-    B.d0 = d0; B.d1 = d1; B.d2 = d2; B.d3 = d3;
-    B.i0 = i0; B.i1 = i1; B.i2 = i2; B.i3 = i3;
-    B.w10 = -l10; B.w21 = -l21; B.w32 = -l32;
-    B.w20 = l21 * l10 - l20;
-    B.w31 = l32 * l21 - l31;
-    B.w30 = l31 * l10 + l32 * (l20 - l21 * l10) - l30;
-    l[0] = l10; l[1] = l20; l[2] = l21; l[3] = l30; l[4] = l31; l[5] = l32;
-    const double dmin = fmin(fmin(fabs(d0), fabs(d1)), fmin(fabs(d2), fabs(d3)));
-    return !(dmin > 0.0) || !isfinite(d0) || !isfinite(d1) || !isfinite(d2) || !isfinite(d3);
-}
+#include "ldlt32.hpp"
 
 __device__ __forceinline__ void block_ldlt32_b4(double (*Dn)[NB + 1], double* dq, int nb, int tid, double* Wb /* [2][16] */,
                                                 double (*Sp)[4], double (*Lp)[4], int32_t* __restrict__ status) {
@@ -1531,6 +1509,17 @@ __device__ __forceinline__ void block_ldlt32_b4(double (*Dn)[NB + 1], double* dq
         if (cc >= rr || rr >= nb) Dn[rr][cc] = 0.0;
     }
     __syncthreads();
+}
+
+// The shipped 32 x 32 LDL': one wave, matrix-core updates (ldlt32.hpp); -DMGB_LDLT32_B4 selects the 4 x 4-blocked workgroup form.
+__device__ __forceinline__ void block_ldlt32(double (*Dn)[NB + 1], double* dq, int nb, int tid, double* Wb, double (*Sp)[4],
+                                             double (*Lp)[4], int32_t* __restrict__ status) {
+#ifdef MGB_LDLT32_B4
+    block_ldlt32_b4(Dn, dq, nb, tid, Wb, Sp, Lp, status);
+#else
+    (void)Wb; (void)Sp; (void)Lp;
+    block_ldlt32_mfma(Dn, dq, nb, tid, status);
+#endif
 }
 
 // W = L^{-1} for the unit lower triangular 32 x 32 L in Ls (strictly lower part, row-major), all 256
@@ -1611,7 +1600,7 @@ __device__ __forceinline__ void slice_transform(double (*P)[ST + 1], double (*Po
 }
 
 #ifdef MGB_STEP_PROBE      // development probe build only (tools/gpu_probe.py): per-phase timestamps of one step
-#define PROBE(i) do { if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[i] = wall_clock64(); if (!is_la && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[16 + i] = wall_clock64(); } while (0)
+#define PROBE(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) g_probe[i] = wall_clock64(); if (!is_la && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) g_probe[16 + i] = wall_clock64(); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define PROBE(i) do { } while (0)
 #endif
@@ -1651,6 +1640,9 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
     const int nbn = look ? min(NB, k - j1) : 0;
     const int rbase = is_la ? j1 : j1 + ti * ST, cbase = j1 + tj * ST;
     PROBE(0);
+#ifdef MGB_STEP_PROBE
+    if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) g_probe[34] = clock64();
+#endif
     const int fr16 = lane & 15, fk = lane >> 4;
 
     // ---- global loads first: raw panel slices and this wave's part of the C tile -----------------
@@ -1687,7 +1679,7 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
             Dn[rr][c] = (rr >= c && rr < nb) ? W[(j0 + rr) + (int64_t)(j0 + c) * m] : 0.0;
         }
         __syncthreads();
-        block_ldlt32_b4(Dn, dq, nb, tid, colbuf, Sp4, Lp4, is_la ? status : nullptr);
+        block_ldlt32(Dn, dq, nb, tid, colbuf, Sp4, Lp4, is_la ? status : nullptr);
         block_inverse32(Dn, Wv, Tm, tid);
     } else {
         for (int i = tid; i < NB * NB; i += 256) {
@@ -1760,11 +1752,28 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
         double* nslot = dscr + ((int64_t)blockIdx.y * 2 + ((j1 / NB) & 1)) * (NB * NB);
         PROBE(4);
 #ifdef MGB_STEP_PROBE
-        if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[32] = clock64();
+        // cold / warm experiment: the same factorization twice (Dn saved and restored in between)
+        double sv[4];
+        for (int t = 0; t < 4; ++t) { const int i = tid + 256 * t; sv[t] = Dn[i % NB][i / NB]; }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[32] = clock64(); g_probe[36] = wall_clock64(); }
+        __builtin_amdgcn_sched_barrier(0);
+        block_ldlt32(Dn, dq, nbn, tid, colbuf, Sp4, Lp4, nullptr);
+        __builtin_amdgcn_sched_barrier(0);
+        if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[33] = clock64(); g_probe[37] = wall_clock64(); }
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 4; ++t) { const int i = tid + 256 * t; Dn[i % NB][i / NB] = sv[t]; }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[38] = clock64(); g_probe[44] = wall_clock64(); }
+        __builtin_amdgcn_sched_barrier(0);
 #endif
-        block_ldlt32_b4(Dn, dq, nbn, tid, colbuf, Sp4, Lp4, status);
+        block_ldlt32(Dn, dq, nbn, tid, colbuf, Sp4, Lp4, status);
 #ifdef MGB_STEP_PROBE
-        if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64) g_probe[33] = clock64();
+        __builtin_amdgcn_sched_barrier(0);
+        if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[39] = clock64(); g_probe[45] = wall_clock64(); }
+        __builtin_amdgcn_sched_barrier(0);
 #endif
         PROBE(5);
         block_inverse32(Dn, Wv, Tm, tid);
@@ -1774,6 +1783,9 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
             if (rr >= c && rr < nbn) nslot[rr + NB * c] = (rr == c) ? dq[rr] : Wv[rr][c];
         }
         PROBE(7);
+#ifdef MGB_STEP_PROBE
+        if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) g_probe[35] = clock64();
+#endif
         return;
     }
     if (ti == tj) {
@@ -1845,7 +1857,7 @@ __global__ __launch_bounds__(256) void mf_big_diag0(const FrontDev* __restrict__
         Dn[rr][c] = (rr >= c && rr < nb) ? W[rr + (int64_t)c * m] : 0.0;
     }
     __syncthreads();
-    block_ldlt32_b4(Dn, dq, nb, tid, colbuf, Sp4, Lp4, status);
+    block_ldlt32(Dn, dq, nb, tid, colbuf, Sp4, Lp4, status);
     block_inverse32(Dn, Wv, Tm, tid);
     double* slot = dscr + (int64_t)blockIdx.x * 2 * (NB * NB);
     for (int i = tid; i < NB * NB; i += 256) {
@@ -1928,7 +1940,7 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
             }
         }
         __syncthreads();
-        block_ldlt32_b4(Dn, dq, nb, tid, colbuf, Sp4, Lp4, status);
+        block_ldlt32(Dn, dq, nb, tid, colbuf, Sp4, Lp4, status);
         block_inverse32(Dn, Wv, Tm, tid);
         double* slot = dscr + (int64_t)blockIdx.y * 2 * (NB * NB);
         for (int i = tid; i < NB * NB; i += 256) {
@@ -2144,7 +2156,8 @@ __global__ __launch_bounds__(BIGI_THREADS) void mf_fwd_inv(const FrontDev* __res
 }
 
 // backward:  x_j = u_j - M_j G_j,  G[q] = sum over solved rows r of A[r, q] x[r]
-#ifdef MGB_STEP_PROBE      // root front of a sweep: phase timestamps (tools/gpu_probe_bwd.py)
+#ifdef MGB_PROBE_BWD       // root front of a sweep: phase timestamps (tools/gpu_probe_bwd.py; build with -DMGB_STEP_PROBE -DMGB_PROBE_BWD:
+                           // the slots are shared with the mf_big_step probes)
 #define BP(i) do { if (threadIdx.x == 0 && gridDim.x == 1 && fr[first].k > 400) g_probe[(i)] = wall_clock64(); } while (0)
 #else
 #define BP(i) do { } while (0)

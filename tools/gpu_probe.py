@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import mgb_amd as m
 from mgb_amd.device import DeviceMGBProblem
-prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 9), prolongator=m.amg_ruge_stuben(max_coarse=300)), p=1.0)
+prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 9)), p=1.0)
 D = DeviceMGBProblem(prob); P = D.main
 J = len(P.level_sizes) - 1
 z0 = np.ascontiguousarray(prob.g.T).reshape(-1); c = 0.1 * prob.f; s = np.zeros(P.level_sizes[J])
@@ -24,3 +24,6 @@ D.close()
 print("LDLT clock at columns 0,8,16,24 (cycles since col 0):", [int(v[40+i]-v[40]) for i in range(4)], "end:", int(v[33]-v[40]), "start->col0:", int(v[40]-v[32]))
 print("fwd_inv level-6 front (us since entry): after init gather, W ready, wave0 done, rows done, end:", [round((v[48+i]-v[48])*0.01,2) for i in range(1,6)])
 print("fwd_inv level-6 kernel: first start -> last end (us):", (v[57]-v[56])*0.01)
+print("shader clock over the look-ahead workgroup: %d cycles in %.2f us -> %.2f GHz" % (v[35] - v[34], (v[7] - v[0]) * 0.01, (v[35] - v[34]) / ((v[7] - v[0]) * 10.0)))
+print("32x32 LDLt in the look-ahead workgroup, first run: %d cycles / %.2f us; second run (same code, same data): %d cycles / %.2f us" % (v[33] - v[32], (v[37] - v[36]) * 0.01, v[39] - v[38], (v[45] - v[44]) * 0.01))
+print("absolute (us since LA entry): LDLt#1 start %.2f end %.2f, LDLt#2 start %.2f end %.2f" % tuple((v[i] - v[0]) * 0.01 for i in (36, 37, 44, 45)))
