@@ -4,8 +4,8 @@
 
 struct Blk4 { double w10, w20, w21, w30, w31, w32, i0, i1, i2, i3, d0, d1, d2, d3; };
 
-__device__ __forceinline__ bool ldlt4_serial(double a00, double a10, double a11, double a20, double a21, double a22, double a30,
-                                             double a31, double a32, double a33, Blk4& B, double (&l)[6]) {
+__device__ __forceinline__ void ldlt4_core(double a00, double a10, double a11, double a20, double a21, double a22, double a30,
+                                           double a31, double a32, double a33, Blk4& B, double (&l)[6]) {
     const double d0 = a00, i0 = fast_recip(d0);
     const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
     const double d1 = a11 - l10 * a10, i1 = fast_recip(d1);
@@ -22,10 +22,13 @@ __device__ __forceinline__ bool ldlt4_serial(double a00, double a10, double a11,
     B.w31 = l32 * l21 - l31;
     B.w30 = l31 * l10 + l32 * (l20 - l21 * l10) - l30;
     l[0] = l10; l[1] = l20; l[2] = l21; l[3] = l30; l[4] = l31; l[5] = l32;
-    const double dmin = fmin(fmin(fabs(d0), fabs(d1)), fmin(fabs(d2), fabs(d3)));
-    return !(dmin > 0.0) || !isfinite(d0) || !isfinite(d1) || !isfinite(d2) || !isfinite(d3);
 }
-
+__device__ __forceinline__ bool ldlt4_serial(double a00, double a10, double a11, double a20, double a21, double a22, double a30,
+                                             double a31, double a32, double a33, Blk4& B, double (&l)[6]) {
+    ldlt4_core(a00, a10, a11, a20, a21, a22, a30, a31, a32, a33, B, l);
+    const double dmin = fmin(fmin(fabs(B.d0), fabs(B.d1)), fmin(fabs(B.d2), fabs(B.d3)));
+    return !(dmin > 0.0) || !isfinite(B.d0) || !isfinite(B.d1) || !isfinite(B.d2) || !isfinite(B.d3);
+}
 
 // The lower triangle lives in three 16 x 16 accumulator tiles of v_mfma_f64_16x16x4 (c00: rows/cols 0-15, c10: rows 16-31 x
 // cols 0-15, c11: rows/cols 16-31): lane (fr = lane & 15, fk = lane >> 4) holds entry (row fr, col 4 i + fk) of a tile in
@@ -51,7 +54,7 @@ __device__ __forceinline__ void block_ldlt32_mfma(double (*Dn)[32 + 1], double* 
             c10[i] = Dn[16 + fr][4 * i + fk];
             c11[i] = Dn[16 + fr][16 + 4 * i + fk];
         }
-        bool bad = false;
+        double dmin = 1.0, dnan = 0.0;             // smallest |pivot| of the block; a non-finite pivot turns dnan into NaN
 #pragma unroll
         for (int b = 0; b < N32 / 4; ++b) {
             const int T = b >> 2, i = b & 3, cb = 4 * b, cn = cb + 4;
@@ -64,7 +67,9 @@ __device__ __forceinline__ void block_ldlt32_mfma(double (*Dn)[32 + 1], double* 
                          a33 = readlane_f64(src, l0 + 3 + 48);
             Blk4 B;
             double l[6];
-            bad |= ldlt4_serial(a00, a10, a11, a20, a21, a22, a30, a31, a32, a33, B, l);
+            ldlt4_core(a00, a10, a11, a20, a21, a22, a30, a31, a32, a33, B, l);
+            dmin = fmin(fmin(dmin, fabs(B.d0)), fmin(fabs(B.d1), fmin(fabs(B.d2), fabs(B.d3))));
+            dnan = fma(B.d0, 0.0, fma(B.d1, 0.0, fma(B.d2, 0.0, fma(B.d3, 0.0, dnan))));
             if (tid == 0) {
                 dq[cb] = B.d0; dq[cb + 1] = B.d1; dq[cb + 2] = B.d2; dq[cb + 3] = B.d3;
                 Dn[cb + 1][cb] = l[0]; Dn[cb + 2][cb] = l[1]; Dn[cb + 2][cb + 1] = l[2];
@@ -102,6 +107,7 @@ __device__ __forceinline__ void block_ldlt32_mfma(double (*Dn)[32 + 1], double* 
                 c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(lB, -sB, c11, 0, 0, 0);
             }
         }
+        const bool bad = !(dmin > 0.0) || !(dnan == 0.0);      // same rule as ldlt4_serial: a zero or non-finite pivot
         if (bad && status && tid == 0) atomicOr(status, 1);
     }
     __syncthreads();

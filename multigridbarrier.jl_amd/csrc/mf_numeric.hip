@@ -1698,11 +1698,13 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
     __syncthreads();
     PROBE(1);
     if (tid < NB) rdq[tid] = 1.0 / dq[tid];
-    if (is_la) {
-        // home of block j (nobody reads it during this step): M_j = W_j' D_j^{-1} W_j, the inverse of the updated
-        // diagonal block -- the triangular sweeps need nothing else of the block (mf_fwd_inv / mf_bwd_inv).
-        // Strictly upper triangle = off-diagonal of M_j, diagonal of M_j to dvec.  One 16 x 16 tile per wave on the
-        // matrix cores, straight from the accumulators (the tile above the diagonal is the mirror image: skipped).
+    // home of block j (nobody reads it during this step): M_j = W_j' D_j^{-1} W_j, the inverse of the updated
+    // diagonal block -- the triangular sweeps need nothing else of the block (mf_fwd_inv / mf_bwd_inv).
+    // Strictly upper triangle = off-diagonal of M_j, diagonal of M_j to dvec.  One 16 x 16 tile per wave on the
+    // matrix cores, straight from the accumulators (the tile above the diagonal is the mirror image: skipped).
+    // Written by tile workgroup 0 (done at 6 us, every workgroup has W_j staged) rather than by the look-ahead
+    // workgroup, whose 1.7 us for it sat on the critical path of the pivot chain; steps without tiles keep it there.
+    if (is_la ? T == 0 : blockIdx.x == 0) {          // T is this front's own tile count (a batch is launched for its largest front)
         {
             const int rt = wave & 1, ct = wave >> 1;
             if (ct <= rt) {
@@ -1720,8 +1722,8 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
                 }
             }
         }
-        if (!look) return;
     }
+    if (is_la && !look) return;
     __syncthreads();
     PROBE(2);
     // ---- S (into Pa) and L (into Pb) ---------------------------------------------------------------
