@@ -41,10 +41,57 @@ __device__ __forceinline__ bool ldlt4_serial(double a00, double a10, double a11,
 // the diagonal and beyond nb; on return the strictly lower unit factor (zeros elsewhere), dq the pivots (1 beyond nb).
 // Every thread of the 256-thread workgroup must call this.
 typedef double ld_double4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void block_ldlt32_mfma(double (*Dn)[32 + 1], double* dq, int nb, int tid, int32_t* __restrict__ status) {
+// WITH_INV: the unit-lower inverse W = L^{-1} is built alongside, one row block behind the factorization, by wave 1
+// (W[b,:] = W4_b (E_b - L[b,<b] W[<b,:]): a block forward substitution whose inputs -- the rows of L left of the diagonal
+// block, final one step earlier, and W4_b, a by-product of the 4 x 4 step -- wave 0 publishes through LDS and a step
+// counter; wave 0 never waits).  Wv receives W with unit diagonal and zero upper triangle, ~0.3 us after the last pivot
+// (the recursive-doubling inverse that ran after the factorization took 1.6 us and seven workgroup barriers).
+template <bool WITH_INV>
+__device__ __forceinline__ void block_ldlt32_mfma_t(double (*Dn)[32 + 1], double* dq, int nb, int tid, double (*Wv)[32 + 1],
+                                                    int32_t* __restrict__ status) {
     constexpr int N32 = 32;
+    __shared__ double w4s[N32 / 4][6];
+    __shared__ int ldl_step;
     if (tid < N32 && tid >= nb) Dn[tid][tid] = 1.0;      // identity padding keeps the recurrences free of special cases
+    if (WITH_INV) {
+        for (int i = tid; i < N32 * N32; i += 256) Wv[i / N32][i % N32] = (i / N32 == i % N32) ? 1.0 : 0.0;
+        if (tid == 0) ldl_step = 0;
+    }
     __syncthreads();
+    if (WITH_INV && tid >= 64 && tid < 128) {
+        const int c = tid & 31, half = (tid >> 5) & 1;   // one column of W per lane pair; the two half-waves split the k range
+        for (int b = 0; b < N32 / 4; ++b) {
+            while (__atomic_load_n(&ldl_step, __ATOMIC_RELAXED) < b + 1) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int cb = 4 * b;
+            const double w10 = w4s[b][0], w20 = w4s[b][1], w21 = w4s[b][2], w30 = w4s[b][3], w31 = w4s[b][4], w32 = w4s[b][5];
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            for (int k0 = 4 * half; k0 < cb; k0 += 8) {      // W[k][c] = 0 for k < c: the uniform trip count is exact
+                double wk[4], la[4], lb[4], lc[4], ld[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                 // twenty LDS reads in flight (a rolled loop paid a latency per k)
+                    wk[u] = Wv[k0 + u][c];
+                    la[u] = Dn[cb][k0 + u]; lb[u] = Dn[cb + 1][k0 + u]; lc[u] = Dn[cb + 2][k0 + u]; ld[u] = Dn[cb + 3][k0 + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { t0 -= la[u] * wk[u]; t1 -= lb[u] * wk[u]; t2 -= lc[u] * wk[u]; t3 -= ld[u] * wk[u]; }
+            }
+            t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64); t3 += __shfl_xor(t3, 32, 64);
+            if (half == 0) {
+                if (c < cb) {
+                    Wv[cb][c] = t0;
+                    Wv[cb + 1][c] = t1 + w10 * t0;
+                    Wv[cb + 2][c] = t2 + w20 * t0 + w21 * t1;
+                    Wv[cb + 3][c] = t3 + w30 * t0 + w31 * t1 + w32 * t2;
+                } else if (c < cb + 4) {                      // the diagonal block of W is W4_b itself
+                    const int cc = c - cb;
+                    if (cc == 0) { Wv[cb + 1][c] = w10; Wv[cb + 2][c] = w20; Wv[cb + 3][c] = w30; }
+                    else if (cc == 1) { Wv[cb + 2][c] = w21; Wv[cb + 3][c] = w31; }
+                    else if (cc == 2) { Wv[cb + 3][c] = w32; }
+                }
+            }
+        }
+    }
     if (tid < 64) {
         const int fr = tid & 15, fk = tid >> 4;
         ld_double4_t c00, c10, c11;
@@ -74,6 +121,12 @@ __device__ __forceinline__ void block_ldlt32_mfma(double (*Dn)[32 + 1], double* 
                 dq[cb] = B.d0; dq[cb + 1] = B.d1; dq[cb + 2] = B.d2; dq[cb + 3] = B.d3;
                 Dn[cb + 1][cb] = l[0]; Dn[cb + 2][cb] = l[1]; Dn[cb + 2][cb + 1] = l[2];
                 Dn[cb + 3][cb] = l[3]; Dn[cb + 3][cb + 1] = l[4]; Dn[cb + 3][cb + 2] = l[5];
+                if (WITH_INV) {
+                    w4s[b][0] = B.w10; w4s[b][1] = B.w20; w4s[b][2] = B.w21; w4s[b][3] = B.w30; w4s[b][4] = B.w31; w4s[b][5] = B.w32;
+                    // rows of L left of block b were final after step b - 1 (this wave's LDS stores stay ordered)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __atomic_store_n(&ldl_step, b + 1, __ATOMIC_RELAXED);
+                }
             }
             // panel rows of one tile row: x = this lane's entry (row, cb + fk); returns the operands s(row)[fk], l(row)[fk].
             // (s = a W4' as one more MFMA with W4 padded into the A operand lands in the right lanes too, but its latency
@@ -117,4 +170,11 @@ __device__ __forceinline__ void block_ldlt32_mfma(double (*Dn)[32 + 1], double* 
         if (cc >= rr || rr >= nb) Dn[rr][cc] = 0.0;
     }
     __syncthreads();
+}
+__device__ __forceinline__ void block_ldlt32_mfma(double (*Dn)[32 + 1], double* dq, int nb, int tid, int32_t* __restrict__ status) {
+    block_ldlt32_mfma_t<false>(Dn, dq, nb, tid, nullptr, status);
+}
+__device__ __forceinline__ void block_ldlt32_inv_mfma(double (*Dn)[32 + 1], double* dq, int nb, int tid, double (*Wv)[32 + 1],
+                                                      int32_t* __restrict__ status) {
+    block_ldlt32_mfma_t<true>(Dn, dq, nb, tid, Wv, status);
 }

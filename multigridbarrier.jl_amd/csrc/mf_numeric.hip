@@ -1771,14 +1771,20 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
         if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[38] = clock64(); g_probe[44] = wall_clock64(); }
         __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef MGB_LDLT32_FUSED_INV
+        block_ldlt32_inv_mfma(Dn, dq, nbn, tid, Wv, status);
+#else
         block_ldlt32(Dn, dq, nbn, tid, colbuf, Sp4, Lp4, status);
+#endif
 #ifdef MGB_STEP_PROBE
         __builtin_amdgcn_sched_barrier(0);
         if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[39] = clock64(); g_probe[45] = wall_clock64(); }
         __builtin_amdgcn_sched_barrier(0);
 #endif
         PROBE(5);
+#ifndef MGB_LDLT32_FUSED_INV
         block_inverse32(Dn, Wv, Tm, tid);
+#endif
         PROBE(6);
         for (int i = tid; i < NB * NB; i += 256) {        // slot: diagonal d, strictly lower W (column-major)
             const int rr = i % NB, c = i / NB;

@@ -22,8 +22,9 @@ __device__ __forceinline__ double fast_recip(double d) {
 }
 #include "../../multigridbarrier.jl_amd/csrc/ldlt32.hpp"
 
-__global__ __launch_bounds__(256) void test_kernel(const double* A, int nb, double* Lout, double* dout, long long* cyc, int32_t* status) {
+__global__ __launch_bounds__(256) void test_kernel(const double* A, int nb, double* Lout, double* dout, long long* cyc, int32_t* status, double* Wout) {
     __shared__ double Dn[32][33];
+    __shared__ double Wv[32][33];
     __shared__ double dq[32];
     const int tid = threadIdx.x;
     for (int rep = 0; rep < 3; ++rep) {
@@ -33,12 +34,12 @@ __global__ __launch_bounds__(256) void test_kernel(const double* A, int nb, doub
         }
         __syncthreads();
         const long long t0 = clock64();
-        block_ldlt32_mfma(Dn, dq, nb, tid, status);
+        block_ldlt32_inv_mfma(Dn, dq, nb, tid, Wv, status);
         const long long t1 = clock64();
         if (tid == 0) cyc[rep] = t1 - t0;
         __syncthreads();
     }
-    for (int i = tid; i < 32 * 32; i += 256) Lout[i] = Dn[i / 32][i % 32];
+    for (int i = tid; i < 32 * 32; i += 256) { Lout[i] = Dn[i / 32][i % 32]; Wout[i] = Wv[i / 32][i % 32]; }
     if (tid < 32) dout[tid] = dq[tid];
 }
 
@@ -60,11 +61,13 @@ int main() {
             for (int r = j + 1; r < nb; ++r)
                 for (int c = j + 1; c <= r; ++c) M[r * 32 + c] -= L[r * 32 + j] * d[j] * L[c * 32 + j];
         }
-        double *dA, *dL, *dd; long long* dc; int32_t* ds;
-        hipMalloc(&dA, 8 * 1024); hipMalloc(&dL, 8 * 1024); hipMalloc(&dd, 8 * 32); hipMalloc(&dc, 8 * 4); hipMalloc(&ds, 4);
+        double *dA, *dL, *dd, *dW; long long* dc; int32_t* ds;
+        hipMalloc(&dA, 8 * 1024); hipMalloc(&dL, 8 * 1024); hipMalloc(&dd, 8 * 32); hipMalloc(&dc, 8 * 4); hipMalloc(&ds, 4); hipMalloc(&dW, 8 * 1024);
         hipMemcpy(dA, A.data(), 8 * 1024, hipMemcpyHostToDevice);
         hipMemset(ds, 0, 4);
-        hipLaunchKernelGGL(test_kernel, dim3(1), dim3(256), 0, 0, dA, nb, dL, dd, dc, ds);
+        hipLaunchKernelGGL(test_kernel, dim3(1), dim3(256), 0, 0, dA, nb, dL, dd, dc, ds, dW);
+        std::vector<double> gW(1024);
+        hipMemcpy(gW.data(), dW, 8 * 1024, hipMemcpyDeviceToHost);
         std::vector<double> gL(1024), gd(32); long long cyc[4]; int32_t st;
         hipMemcpy(gL.data(), dL, 8 * 1024, hipMemcpyDeviceToHost); hipMemcpy(gd.data(), dd, 8 * 32, hipMemcpyDeviceToHost);
         hipMemcpy(cyc, dc, 8 * 3, hipMemcpyDeviceToHost); hipMemcpy(&st, ds, 4, hipMemcpyDeviceToHost);
@@ -77,20 +80,28 @@ int main() {
             }
             ed = fmax(ed, fabs(gd[r] - (r < nb ? d[r] : 1.0)) / fabs(r < nb ? d[r] : 1.0));
         }
-        const bool ok = eL < 1e-13 && ed < 1e-13 && up == 0.0 && st == 0;
-        printf("nb=%2d  max|L-Lref|=%.2e  max rel|d-dref|=%.2e  upper/diag residue=%.1e  status=%d  cycles %lld %lld %lld  %s\n", nb, eL, ed, up, st,
+        double eW = 0.0;      // (I + L) W = I with the device's own L; W unit lower, zero above the diagonal
+        for (int r = 0; r < 32; ++r)
+            for (int c = 0; c < 32; ++c) {
+                double acc = gW[r * 32 + c];
+                for (int k = 0; k < r; ++k) acc += gL[r * 32 + k] * gW[k * 32 + c];
+                eW = fmax(eW, fabs(acc - (r == c ? 1.0 : 0.0)));
+                if (c > r) eW = fmax(eW, fabs(gW[r * 32 + c]));
+            }
+        const bool ok = eL < 1e-13 && ed < 1e-13 && up == 0.0 && st == 0 && eW < 1e-13;
+        printf("nb=%2d  max|L-Lref|=%.2e  max rel|d-dref|=%.2e  |LW-I|=%.2e  upper/diag residue=%.1e  status=%d  cycles %lld %lld %lld  %s\n", nb, eL, ed, eW, up, st,
                cyc[0], cyc[1], cyc[2], ok ? "ok" : "FAIL");
         fails += !ok;
-        hipFree(dA); hipFree(dL); hipFree(dd); hipFree(dc); hipFree(ds);
+        hipFree(dA); hipFree(dL); hipFree(dd); hipFree(dc); hipFree(ds); hipFree(dW);
     }
     // a zero pivot must raise the status flag
     {
         std::vector<double> A(32 * 32, 0.0);
         for (int r = 0; r < 32; ++r) A[r * 32 + r] = (r == 7) ? 0.0 : 3.0;
-        double *dA, *dL, *dd; long long* dc; int32_t* ds;
-        hipMalloc(&dA, 8 * 1024); hipMalloc(&dL, 8 * 1024); hipMalloc(&dd, 8 * 32); hipMalloc(&dc, 8 * 4); hipMalloc(&ds, 4);
+        double *dA, *dL, *dd, *dW; long long* dc; int32_t* ds;
+        hipMalloc(&dA, 8 * 1024); hipMalloc(&dL, 8 * 1024); hipMalloc(&dd, 8 * 32); hipMalloc(&dc, 8 * 4); hipMalloc(&ds, 4); hipMalloc(&dW, 8 * 1024);
         hipMemcpy(dA, A.data(), 8 * 1024, hipMemcpyHostToDevice); hipMemset(ds, 0, 4);
-        hipLaunchKernelGGL(test_kernel, dim3(1), dim3(256), 0, 0, dA, 32, dL, dd, dc, ds);
+        hipLaunchKernelGGL(test_kernel, dim3(1), dim3(256), 0, 0, dA, 32, dL, dd, dc, ds, dW);
         int32_t st; hipMemcpy(&st, ds, 4, hipMemcpyDeviceToHost);
         printf("zero pivot: status=%d %s\n", st, st == 1 ? "ok" : "FAIL");
         fails += st != 1;
