@@ -1511,7 +1511,15 @@ __device__ __forceinline__ void block_ldlt32_b4(double (*Dn)[NB + 1], double* dq
     __syncthreads();
 }
 
-// The shipped 32 x 32 LDL': one wave, matrix-core updates (ldlt32.hpp); -DMGB_LDLT32_B4 selects the 4 x 4-blocked workgroup form.
+// The shipped 32 x 32 LDL': one wave, matrix-core updates (ldlt32.hpp); -DMGB_LDLT32_B4 selects the 4 x 4-blocked workgroup form
+// (whose 3 KB of LDS scratch kept mf_big_step at two workgroups per compute unit: without it three fit).
+#ifdef MGB_LDLT32_B4
+#define MGB_LDLT_SCRATCH_DECL __shared__ __attribute__((aligned(16))) double colbuf[4 * NB]; __shared__ double Sp4[NB][4], Lp4[NB][4];
+#define MGB_LDLT_SCRATCH colbuf, Sp4, Lp4
+#else
+#define MGB_LDLT_SCRATCH_DECL
+#define MGB_LDLT_SCRATCH nullptr, nullptr, nullptr
+#endif
 __device__ __forceinline__ void block_ldlt32(double (*Dn)[NB + 1], double* dq, int nb, int tid, double* Wb, double (*Sp)[4],
                                              double (*Lp)[4], int32_t* __restrict__ status) {
 #ifdef MGB_LDLT32_B4
@@ -1605,7 +1613,7 @@ __device__ __forceinline__ void slice_transform(double (*P)[ST + 1], double (*Po
 #define PROBE(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ fr, int32_t first, int j0,
+__global__ __launch_bounds__(256, 3) void mf_big_step(const FrontDev* __restrict__ fr, int32_t first, int j0,
                                                    double* __restrict__ arena, double* __restrict__ dscr,
                                                    double* __restrict__ dvec, int32_t* __restrict__ status,
                                                    int do_diag) {
@@ -1613,8 +1621,7 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
     __shared__ double Dn[NB][NB + 1];
     __shared__ double Tm[16][17];
     __shared__ double dq[NB], rdq[NB];
-    __shared__ __attribute__((aligned(16))) double colbuf[4 * NB];
-    __shared__ double Sp4[NB][4], Lp4[NB][4];
+    MGB_LDLT_SCRATCH_DECL
     __shared__ double Pa[NB][ST + 1];
     __shared__ double Pb[NB][ST + 1];
     const FrontDev F = fr[first + blockIdx.y];
@@ -1679,7 +1686,7 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
             Dn[rr][c] = (rr >= c && rr < nb) ? W[(j0 + rr) + (int64_t)(j0 + c) * m] : 0.0;
         }
         __syncthreads();
-        block_ldlt32(Dn, dq, nb, tid, colbuf, Sp4, Lp4, is_la ? status : nullptr);
+        block_ldlt32(Dn, dq, nb, tid, MGB_LDLT_SCRATCH, is_la ? status : nullptr);
         block_inverse32(Dn, Wv, Tm, tid);
     } else {
         for (int i = tid; i < NB * NB; i += 256) {
@@ -1761,7 +1768,7 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
         __builtin_amdgcn_sched_barrier(0);
         if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[32] = clock64(); g_probe[36] = wall_clock64(); }
         __builtin_amdgcn_sched_barrier(0);
-        block_ldlt32(Dn, dq, nbn, tid, colbuf, Sp4, Lp4, nullptr);
+        block_ldlt32(Dn, dq, nbn, tid, MGB_LDLT_SCRATCH, nullptr);
         __builtin_amdgcn_sched_barrier(0);
         if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[33] = clock64(); g_probe[37] = wall_clock64(); }
         __builtin_amdgcn_sched_barrier(0);
@@ -1774,7 +1781,7 @@ __global__ __launch_bounds__(256) void mf_big_step(const FrontDev* __restrict__ 
 #ifdef MGB_LDLT32_FUSED_INV
         block_ldlt32_inv_mfma(Dn, dq, nbn, tid, Wv, status);
 #else
-        block_ldlt32(Dn, dq, nbn, tid, colbuf, Sp4, Lp4, status);
+        block_ldlt32(Dn, dq, nbn, tid, MGB_LDLT_SCRATCH, status);
 #endif
 #ifdef MGB_STEP_PROBE
         __builtin_amdgcn_sched_barrier(0);
@@ -1855,8 +1862,7 @@ __global__ __launch_bounds__(256) void mf_big_diag0(const FrontDev* __restrict__
     __shared__ double Dn[NB][NB + 1];
     __shared__ double Tm[16][17];
     __shared__ double dq[NB];
-    __shared__ __attribute__((aligned(16))) double colbuf[4 * NB];
-    __shared__ double Sp4[NB][4], Lp4[NB][4];
+    MGB_LDLT_SCRATCH_DECL
     const FrontDev F = fr[first + blockIdx.x];
     const int m = F.m, nb = min(NB, F.k), tid = threadIdx.x;
     const double* W = arena + F.F_off;
@@ -1865,7 +1871,7 @@ __global__ __launch_bounds__(256) void mf_big_diag0(const FrontDev* __restrict__
         Dn[rr][c] = (rr >= c && rr < nb) ? W[rr + (int64_t)c * m] : 0.0;
     }
     __syncthreads();
-    block_ldlt32(Dn, dq, nb, tid, colbuf, Sp4, Lp4, status);
+    block_ldlt32(Dn, dq, nb, tid, MGB_LDLT_SCRATCH, status);
     block_inverse32(Dn, Wv, Tm, tid);
     double* slot = dscr + (int64_t)blockIdx.x * 2 * (NB * NB);
     for (int i = tid; i < NB * NB; i += 256) {
@@ -1904,8 +1910,7 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
         __shared__ double Dn[NB][NB + 1];
         __shared__ double Tm[16][17];
         __shared__ double dq[NB];
-        __shared__ __attribute__((aligned(16))) double colbuf[4 * NB];
-        __shared__ double Sp4[NB][4], Lp4[NB][4];
+        MGB_LDLT_SCRATCH_DECL
         __shared__ int32_t inv0[GATHER_MAX_CHILD][NB];
         const int tid = threadIdx.x, nch = F.nchild, nb = min(NB, F.k);
         if (tid < nch) {
@@ -1948,7 +1953,7 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
             }
         }
         __syncthreads();
-        block_ldlt32(Dn, dq, nb, tid, colbuf, Sp4, Lp4, status);
+        block_ldlt32(Dn, dq, nb, tid, MGB_LDLT_SCRATCH, status);
         block_inverse32(Dn, Wv, Tm, tid);
         double* slot = dscr + (int64_t)blockIdx.y * 2 * (NB * NB);
         for (int i = tid; i < NB * NB; i += 256) {
