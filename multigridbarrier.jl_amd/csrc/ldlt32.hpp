@@ -178,3 +178,84 @@ __device__ __forceinline__ void block_ldlt32_inv_mfma(double (*Dn)[32 + 1], doub
                                                       int32_t* __restrict__ status) {
     block_ldlt32_mfma_t<true>(Dn, dq, nb, tid, Wv, status);
 }
+
+// W = L^{-1} for the unit lower triangular 32 x 32 L in Ls (strictly lower part, row-major) by recursive doubling
+//   W21 = -W22 (L21 W11)     for blocks of 4 -> 8 -> 16 -> 32 rows
+// on ONE wave with every product on the matrix cores: the pairs of a level are packed into one 16 x 16 (x K) MFMA with
+// block-diagonal operands -- lane (fr, fk) feeds A[m = fr][k = fk] and B[k = fk][n = fr] and keeps the result registers
+// whose block (m >> log2 s) matches its column's (n >> log2 s).  Operands come from LDS, results go back through it;
+// the only synchronisation inside is the wave's own LDS ordering (the 256-thread form needed seven workgroup barriers:
+// 1.6 us per block on the critical path of the pivot chain).  Wv receives W with unit diagonal and a zero upper triangle.
+// Every thread of the workgroup must call this (two barriers).
+__device__ __forceinline__ void ld_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void block_inverse32_mfma(const double (*Ls)[32 + 1], double (*Wv)[32 + 1], double (*Tm)[17], int tid) {
+    constexpr int N32 = 32;
+    for (int i = tid; i < N32 * N32; i += 256) Wv[i / N32][i % N32] = (i / N32 == i % N32) ? 1.0 : 0.0;
+    __syncthreads();
+    if (tid < 64) {
+        const int fr = tid & 15, fk = tid >> 4;
+        const ld_double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+        if (tid < N32 / 4) {        // 4 x 4 diagonal blocks in closed form
+            const int o = 4 * tid;
+            const double l21 = Ls[o + 1][o], l31 = Ls[o + 2][o], l32 = Ls[o + 2][o + 1];
+            const double l41 = Ls[o + 3][o], l42 = Ls[o + 3][o + 1], l43 = Ls[o + 3][o + 2];
+            Wv[o + 1][o] = -l21;
+            Wv[o + 2][o + 1] = -l32;
+            Wv[o + 3][o + 2] = -l43;
+            Wv[o + 2][o] = l32 * l21 - l31;
+            Wv[o + 3][o + 1] = l43 * l32 - l42;
+            Wv[o + 3][o] = l42 * l21 + l43 * (l31 - l32 * l21) - l41;
+        }
+        ld_wave_lds_sync();
+        {   // s = 4: four pairs, rows 8p .. 8p+7; operand row m <-> (p = m >> 2, i = m & 3), column n <-> (p', j)
+            const int p = fr >> 2, i = fr & 3;
+            ld_double4_t t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[8 * p + 4 + i][8 * p + fk], Wv[8 * p + fk][8 * p + i], zero4, 0, 0, 0);
+            // D[m = fk + 4 r][n = fr]: block of m is r, i = fk; keep r == p (the column's block), j = fr & 3
+            const double tv = p == 0 ? t[0] : (p == 1 ? t[1] : (p == 2 ? t[2] : t[3]));
+            Tm[4 * p + fk][i] = tv;
+            ld_wave_lds_sync();
+            ld_double4_t w = __builtin_amdgcn_mfma_f64_16x16x4f64(Wv[8 * p + 4 + i][8 * p + 4 + fk], Tm[4 * p + fk][i], zero4, 0, 0, 0);
+            const double wv = p == 0 ? w[0] : (p == 1 ? w[1] : (p == 2 ? w[2] : w[3]));
+            Wv[8 * p + 4 + fk][8 * p + i] = -wv;
+            ld_wave_lds_sync();
+        }
+        {   // s = 8: two pairs, rows 16p .. 16p+15; m <-> (p = m >> 3, i = m & 7), n <-> (p', j = n & 7)
+            const int p = fr >> 3, i = fr & 7;
+            ld_double4_t t = zero4;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[16 * p + 8 + i][16 * p + 4 * kb + fk], Wv[16 * p + 4 * kb + fk][16 * p + i], t, 0, 0, 0);
+            // D[m = fk + 4 r][n = fr]: block of m is r >> 1, row in block 4 (r & 1) + fk; keep r >> 1 == p
+            Tm[8 * p + fk][i] = p == 0 ? t[0] : t[2];
+            Tm[8 * p + 4 + fk][i] = p == 0 ? t[1] : t[3];
+            ld_wave_lds_sync();
+            ld_double4_t w = zero4;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                w = __builtin_amdgcn_mfma_f64_16x16x4f64(Wv[16 * p + 8 + i][16 * p + 8 + 4 * kb + fk], Tm[8 * p + 4 * kb + fk][i], w, 0, 0, 0);
+            Wv[16 * p + 8 + fk][16 * p + i] = -(p == 0 ? w[0] : w[2]);
+            Wv[16 * p + 8 + 4 + fk][16 * p + i] = -(p == 0 ? w[1] : w[3]);
+            ld_wave_lds_sync();
+        }
+        {   // s = 16: one pair
+            ld_double4_t t = zero4;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[16 + fr][4 * kb + fk], Wv[4 * kb + fk][fr], t, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tm[fk + 4 * r][fr] = t[r];
+            ld_wave_lds_sync();
+            ld_double4_t w = zero4;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                w = __builtin_amdgcn_mfma_f64_16x16x4f64(Wv[16 + fr][16 + 4 * kb + fk], Tm[4 * kb + fk][fr], w, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Wv[16 + fk + 4 * r][fr] = -w[r];
+        }
+    }
+    __syncthreads();
+}

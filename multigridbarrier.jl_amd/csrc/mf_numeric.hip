@@ -1580,6 +1580,16 @@ __device__ __forceinline__ void block_inverse32(const double (*Ls)[NB + 1], doub
     }
 }
 
+// The shipped inverse: one wave, every product on the matrix cores (ldlt32.hpp: 2.9 k cycles against 3.9 k);
+// -DMGB_INV32_OLD selects the 256-thread recursive doubling above.
+__device__ __forceinline__ void block_inverse32_sel(const double (*Ls)[NB + 1], double (*Wv)[NB + 1], double (*Tm)[17], int tid) {
+#ifdef MGB_INV32_OLD
+    block_inverse32(Ls, Wv, Tm, tid);
+#else
+    block_inverse32_mfma(Ls, Wv, Tm, tid);
+#endif
+}
+
 // S = A W' for a 64-row slice held raw in P[c][rr] (LDS, overwritten in place); wave w owns rows
 // 16w .. 16w+15, so no cross-wave hazard.  scale != nullptr: result columns are multiplied by
 // scale[q] (the reciprocal pivots) and written to Pout (may alias P).
@@ -1687,7 +1697,7 @@ __global__ __launch_bounds__(256, 3) void mf_big_step(const FrontDev* __restrict
         }
         __syncthreads();
         block_ldlt32(Dn, dq, nb, tid, MGB_LDLT_SCRATCH, is_la ? status : nullptr);
-        block_inverse32(Dn, Wv, Tm, tid);
+        block_inverse32_sel(Dn, Wv, Tm, tid);
     } else {
         for (int i = tid; i < NB * NB; i += 256) {
             const int rr = i % NB, c = i / NB;
@@ -1790,7 +1800,7 @@ __global__ __launch_bounds__(256, 3) void mf_big_step(const FrontDev* __restrict
 #endif
         PROBE(5);
 #ifndef MGB_LDLT32_FUSED_INV
-        block_inverse32(Dn, Wv, Tm, tid);
+        block_inverse32_sel(Dn, Wv, Tm, tid);
 #endif
         PROBE(6);
         for (int i = tid; i < NB * NB; i += 256) {        // slot: diagonal d, strictly lower W (column-major)
@@ -1872,7 +1882,7 @@ __global__ __launch_bounds__(256) void mf_big_diag0(const FrontDev* __restrict__
     }
     __syncthreads();
     block_ldlt32(Dn, dq, nb, tid, MGB_LDLT_SCRATCH, status);
-    block_inverse32(Dn, Wv, Tm, tid);
+    block_inverse32_sel(Dn, Wv, Tm, tid);
     double* slot = dscr + (int64_t)blockIdx.x * 2 * (NB * NB);
     for (int i = tid; i < NB * NB; i += 256) {
         const int rr = i % NB, c = i / NB;
@@ -1954,7 +1964,7 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
         }
         __syncthreads();
         block_ldlt32(Dn, dq, nb, tid, MGB_LDLT_SCRATCH, status);
-        block_inverse32(Dn, Wv, Tm, tid);
+        block_inverse32_sel(Dn, Wv, Tm, tid);
         double* slot = dscr + (int64_t)blockIdx.y * 2 * (NB * NB);
         for (int i = tid; i < NB * NB; i += 256) {
             const int rr = i % NB, c = i / NB;

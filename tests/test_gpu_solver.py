@@ -87,3 +87,18 @@ def test_condensed_leaves_reproduce_the_assembled_newton_direction(L, p):
             assert np.linalg.norm(P.solve(J, g) - x) <= 1e-10 * np.linalg.norm(x)
     finally:
         D.close()
+
+
+def test_one_wave_mfma_ldlt32_matches_host_ldlt_and_flags_zero_pivots():
+    """The 32 x 32 LDL' of the pivot chain (csrc/ldlt32.hpp: matrix tiles in MFMA accumulators, one wave, no barriers
+    inside the block) and the inverse built alongside it, in the standalone harness tools/micro/ldlt32_mfma_test.hip:
+    L and d against a host LDL' in double for nb = 32, 31, 17, 16, 5, 1 (identity padding), (I + L) W = I, a clean upper
+    triangle, and the status flag on a zero pivot.  The binary is built by __graft_entry__.build()."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "micro", "ldlt32_mfma_test")
+    if not os.path.exists(exe):
+        pytest.fail("tools/micro/ldlt32_mfma_test is not built: run python __graft_entry__.py")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("nb=") or l.startswith("zero pivot")]
+    assert len(lines) == 7 and all(l.rstrip().endswith("ok") for l in lines), out.stdout

@@ -25,6 +25,8 @@ __device__ __forceinline__ double fast_recip(double d) {
 __global__ __launch_bounds__(256) void test_kernel(const double* A, int nb, double* Lout, double* dout, long long* cyc, int32_t* status, double* Wout) {
     __shared__ double Dn[32][33];
     __shared__ double Wv[32][33];
+    __shared__ double Wv2[32][33];
+    __shared__ double Tm[16][17];
     __shared__ double dq[32];
     const int tid = threadIdx.x;
     for (int rep = 0; rep < 3; ++rep) {
@@ -38,8 +40,13 @@ __global__ __launch_bounds__(256) void test_kernel(const double* A, int nb, doub
         const long long t1 = clock64();
         if (tid == 0) cyc[rep] = t1 - t0;
         __syncthreads();
+        const long long t2 = clock64();
+        block_inverse32_mfma(Dn, Wv2, Tm, tid);
+        const long long t3 = clock64();
+        if (tid == 0) cyc[3] = t3 - t2;
+        __syncthreads();
     }
-    for (int i = tid; i < 32 * 32; i += 256) { Lout[i] = Dn[i / 32][i % 32]; Wout[i] = Wv[i / 32][i % 32]; }
+    for (int i = tid; i < 32 * 32; i += 256) { Lout[i] = Dn[i / 32][i % 32]; Wout[i] = Wv[i / 32][i % 32]; Wout[1024 + i] = Wv2[i / 32][i % 32]; }
     if (tid < 32) dout[tid] = dq[tid];
 }
 
@@ -62,15 +69,15 @@ int main() {
                 for (int c = j + 1; c <= r; ++c) M[r * 32 + c] -= L[r * 32 + j] * d[j] * L[c * 32 + j];
         }
         double *dA, *dL, *dd, *dW; long long* dc; int32_t* ds;
-        hipMalloc(&dA, 8 * 1024); hipMalloc(&dL, 8 * 1024); hipMalloc(&dd, 8 * 32); hipMalloc(&dc, 8 * 4); hipMalloc(&ds, 4); hipMalloc(&dW, 8 * 1024);
+        hipMalloc(&dA, 8 * 1024); hipMalloc(&dL, 8 * 1024); hipMalloc(&dd, 8 * 32); hipMalloc(&dc, 8 * 4); hipMalloc(&ds, 4); hipMalloc(&dW, 8 * 2048);
         hipMemcpy(dA, A.data(), 8 * 1024, hipMemcpyHostToDevice);
         hipMemset(ds, 0, 4);
         hipLaunchKernelGGL(test_kernel, dim3(1), dim3(256), 0, 0, dA, nb, dL, dd, dc, ds, dW);
-        std::vector<double> gW(1024);
-        hipMemcpy(gW.data(), dW, 8 * 1024, hipMemcpyDeviceToHost);
-        std::vector<double> gL(1024), gd(32); long long cyc[4]; int32_t st;
+        std::vector<double> gW(2048);
+        hipMemcpy(gW.data(), dW, 8 * 2048, hipMemcpyDeviceToHost);
+        std::vector<double> gL(1024), gd(32); long long cyc[4] = {0, 0, 0, 0}; int32_t st;
         hipMemcpy(gL.data(), dL, 8 * 1024, hipMemcpyDeviceToHost); hipMemcpy(gd.data(), dd, 8 * 32, hipMemcpyDeviceToHost);
-        hipMemcpy(cyc, dc, 8 * 3, hipMemcpyDeviceToHost); hipMemcpy(&st, ds, 4, hipMemcpyDeviceToHost);
+        hipMemcpy(cyc, dc, 8 * 4, hipMemcpyDeviceToHost); hipMemcpy(&st, ds, 4, hipMemcpyDeviceToHost);
         double eL = 0.0, ed = 0.0, up = 0.0;
         for (int r = 0; r < 32; ++r) {
             for (int c = 0; c < 32; ++c) {
@@ -88,9 +95,17 @@ int main() {
                 eW = fmax(eW, fabs(acc - (r == c ? 1.0 : 0.0)));
                 if (c > r) eW = fmax(eW, fabs(gW[r * 32 + c]));
             }
-        const bool ok = eL < 1e-13 && ed < 1e-13 && up == 0.0 && st == 0 && eW < 1e-13;
-        printf("nb=%2d  max|L-Lref|=%.2e  max rel|d-dref|=%.2e  |LW-I|=%.2e  upper/diag residue=%.1e  status=%d  cycles %lld %lld %lld  %s\n", nb, eL, ed, eW, up, st,
-               cyc[0], cyc[1], cyc[2], ok ? "ok" : "FAIL");
+        double eW2 = 0.0;     // the stand-alone matrix-core inverse of the same L
+        for (int r = 0; r < 32; ++r)
+            for (int c = 0; c < 32; ++c) {
+                double acc = gW[1024 + r * 32 + c];
+                for (int k = 0; k < r; ++k) acc += gL[r * 32 + k] * gW[1024 + k * 32 + c];
+                eW2 = fmax(eW2, fabs(acc - (r == c ? 1.0 : 0.0)));
+                if (c > r) eW2 = fmax(eW2, fabs(gW[1024 + r * 32 + c]));
+            }
+        const bool ok = eL < 1e-13 && ed < 1e-13 && up == 0.0 && st == 0 && eW < 1e-13 && eW2 < 1e-13;
+        printf("nb=%2d  max|L-Lref|=%.2e  max rel|d-dref|=%.2e  |LW-I|=%.2e  |LW2-I|=%.2e  upper/diag residue=%.1e  status=%d  cycles %lld %lld %lld  inverse alone %lld  %s\n", nb, eL, ed, eW, eW2, up, st,
+               cyc[0], cyc[1], cyc[2], cyc[3], ok ? "ok" : "FAIL");
         fails += !ok;
         hipFree(dA); hipFree(dL); hipFree(dd); hipFree(dc); hipFree(ds); hipFree(dW);
     }
@@ -99,7 +114,7 @@ int main() {
         std::vector<double> A(32 * 32, 0.0);
         for (int r = 0; r < 32; ++r) A[r * 32 + r] = (r == 7) ? 0.0 : 3.0;
         double *dA, *dL, *dd, *dW; long long* dc; int32_t* ds;
-        hipMalloc(&dA, 8 * 1024); hipMalloc(&dL, 8 * 1024); hipMalloc(&dd, 8 * 32); hipMalloc(&dc, 8 * 4); hipMalloc(&ds, 4); hipMalloc(&dW, 8 * 1024);
+        hipMalloc(&dA, 8 * 1024); hipMalloc(&dL, 8 * 1024); hipMalloc(&dd, 8 * 32); hipMalloc(&dc, 8 * 4); hipMalloc(&ds, 4); hipMalloc(&dW, 8 * 2048);
         hipMemcpy(dA, A.data(), 8 * 1024, hipMemcpyHostToDevice); hipMemset(ds, 0, 4);
         hipLaunchKernelGGL(test_kernel, dim3(1), dim3(256), 0, 0, dA, 32, dL, dd, dc, ds, dW);
         int32_t st; hipMemcpy(&st, ds, 4, hipMemcpyDeviceToHost);
