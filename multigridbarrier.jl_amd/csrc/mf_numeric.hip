@@ -1923,6 +1923,15 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
         MGB_LDLT_SCRATCH_DECL
         __shared__ int32_t inv0[GATHER_MAX_CHILD][NB];
         const int tid = threadIdx.x, nch = F.nchild, nb = min(NB, F.k);
+        // the first batch of A entries of the block (cp -> a_dst / a_src -> Hval: three dependent loads) is requested before
+        // the children's chain (children -> descriptor -> rel -> arena: four more) instead of after it
+        int a_d0 = -1;
+        double a_v0 = 0.0;
+        const int a_end = (a_colptr + F.acol_off)[nb];
+        if (tid < a_end) {
+            a_d0 = a_dst[F.a_off + tid];
+            a_v0 = Hval[a_src[F.a_off + tid]];
+        }
         if (tid < nch) {
             const FrontDev C = fr[children[F.child_off + tid]];
             cU[tid] = C.F_off + (int64_t)C.k * C.m + C.k;
@@ -1954,10 +1963,12 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
         }
         __syncthreads();
         {
-            const int32_t* cp = a_colptr + F.acol_off;
-            const int end = cp[nb];
             const int32_t* ad = a_dst + F.a_off;
-            for (int t = tid; t < end; t += 256) {
+            if (a_d0 >= 0) {
+                const int lu = a_d0 % m, lv = a_d0 / m;
+                if (lu < nb) Dn[lu][lv] += a_v0;
+            }
+            for (int t = tid + 256; t < a_end; t += 256) {
                 const int d = ad[t], lu = d % m, lv = d / m;
                 if (lu < nb) Dn[lu][lv] += Hval[a_src[F.a_off + t]];
             }
