@@ -106,6 +106,16 @@ __device__ __forceinline__ void block_ldlt32_mfma_t(double (*Dn)[32 + 1], double
         for (int b = 0; b < N32 / 4; ++b) {
             const int T = b >> 2, i = b & 3, cb = 4 * b, cn = cb + 4;
             const double src = T == 0 ? c00[i] : c11[i];
+            // the rows' four panel entries through the crossbar first: their latency runs under the 4 x 4 recurrence
+            double pa[2][4];
+            {
+                const double xa = T == 0 ? c00[i] : c11[i], xb = c10[i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pa[0][q] = __shfl(xa, fr + 16 * q, 64);
+                    pa[1][q] = (T == 0) ? __shfl(xb, fr + 16 * q, 64) : 0.0;
+                }
+            }
             const int l0 = 4 * i;                        // lane of entry (cb, cb); (cb + rr, cb + cc) is lane l0 + rr + 16 cc
             const double a00 = readlane_f64(src, l0);
             const double a10 = readlane_f64(src, l0 + 1), a11 = readlane_f64(src, l0 + 1 + 16);
@@ -117,6 +127,34 @@ __device__ __forceinline__ void block_ldlt32_mfma_t(double (*Dn)[32 + 1], double
             ldlt4_core(a00, a10, a11, a20, a21, a22, a30, a31, a32, a33, B, l);
             dmin = fmin(fmin(dmin, fabs(B.d0)), fmin(fabs(B.d1), fmin(fabs(B.d2), fabs(B.d3))));
             dnan = fma(B.d0, 0.0, fma(B.d1, 0.0, fma(B.d2, 0.0, fma(B.d3, 0.0, dnan))));
+            // panel rows of one tile row from the gathered entries: the operands s(row)[fk], l(row)[fk] of the update
+            const double iv = fk == 0 ? B.i0 : (fk == 1 ? B.i1 : (fk == 2 ? B.i2 : B.i3));
+            auto panel = [&](const double (&a)[4], int rowbase, double& ms, double& ml) {
+                const double s0 = a[0];
+                const double s1 = a[1] + a[0] * B.w10;
+                const double s2 = a[2] + a[0] * B.w20 + a[1] * B.w21;
+                const double s3 = a[3] + a[0] * B.w30 + a[1] * B.w31 + a[2] * B.w32;
+                const double sv = fk == 0 ? s0 : (fk == 1 ? s1 : (fk == 2 ? s2 : s3));
+                const double lv = sv * iv;
+                const int row = rowbase + fr;
+                const bool valid = row >= cn;             // rows above the block are finished, rows inside it come from the 4 x 4
+                ms = valid ? sv : 0.0;
+                ml = valid ? lv : 0.0;
+                if (valid) Dn[row][cb + fk] = lv;
+            };
+            if (T == 0) {
+                double sA, lA, sB, lB;
+                panel(pa[0], 0, sA, lA);
+                panel(pa[1], 16, sB, lB);
+                if (cn < 16) c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lA, -sA, c00, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(lA, -sB, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(lB, -sB, c11, 0, 0, 0);
+            } else if (cn < N32) {
+                double sB, lB;
+                panel(pa[0], 16, sB, lB);
+                c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(lB, -sB, c11, 0, 0, 0);
+            }
+            // pivots and the block's own multipliers (and, WITH_INV, the hand-off to the inverse's wave): after the update is issued
             if (tid == 0) {
                 dq[cb] = B.d0; dq[cb + 1] = B.d1; dq[cb + 2] = B.d2; dq[cb + 3] = B.d3;
                 Dn[cb + 1][cb] = l[0]; Dn[cb + 2][cb] = l[1]; Dn[cb + 2][cb + 1] = l[2];
@@ -127,37 +165,6 @@ __device__ __forceinline__ void block_ldlt32_mfma_t(double (*Dn)[32 + 1], double
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __atomic_store_n(&ldl_step, b + 1, __ATOMIC_RELAXED);
                 }
-            }
-            // panel rows of one tile row: x = this lane's entry (row, cb + fk); returns the operands s(row)[fk], l(row)[fk].
-            // (s = a W4' as one more MFMA with W4 padded into the A operand lands in the right lanes too, but its latency
-            // on the dependent path is longer than the four crossbar exchanges: 11.7k against 11.2k cycles per block.)
-            auto panel = [&](double x, int rowbase, double& ms, double& ml) {
-                const double a0 = __shfl(x, fr, 64), a1 = __shfl(x, fr + 16, 64), a2 = __shfl(x, fr + 32, 64),
-                             a3 = __shfl(x, fr + 48, 64);
-                const double s0 = a0;
-                const double s1 = a1 + a0 * B.w10;
-                const double s2 = a2 + a0 * B.w20 + a1 * B.w21;
-                const double s3 = a3 + a0 * B.w30 + a1 * B.w31 + a2 * B.w32;
-                const double sv = fk == 0 ? s0 : (fk == 1 ? s1 : (fk == 2 ? s2 : s3));
-                const double iv = fk == 0 ? B.i0 : (fk == 1 ? B.i1 : (fk == 2 ? B.i2 : B.i3));
-                const double lv = sv * iv;
-                const int row = rowbase + fr;
-                const bool valid = row >= cn;             // rows above the block are finished, rows inside it come from the 4 x 4
-                ms = valid ? sv : 0.0;
-                ml = valid ? lv : 0.0;
-                if (valid) Dn[row][cb + fk] = lv;
-            };
-            if (T == 0) {
-                double sA, lA, sB, lB;
-                panel(c00[i], 0, sA, lA);
-                panel(c10[i], 16, sB, lB);
-                if (cn < 16) c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lA, -sA, c00, 0, 0, 0);
-                c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(lA, -sB, c10, 0, 0, 0);
-                c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(lB, -sB, c11, 0, 0, 0);
-            } else if (cn < N32) {
-                double sB, lB;
-                panel(c11[i], 16, sB, lB);
-                c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(lB, -sB, c11, 0, 0, 0);
             }
         }
         const bool bad = !(dmin > 0.0) || !(dnan == 0.0);      // same rule as ldlt4_serial: a zero or non-finite pivot
