@@ -8,9 +8,38 @@
 #include <stdexcept>
 #include <unordered_map>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <thread>
+
 namespace mgbhip {
 
 namespace {
+
+// Host threads for the embarrassingly parallel parts of the analysis (clique tests of a peeling round, neighbourhood
+// hashes, the A scatter lists): the results are bitwise those of the serial loops.  MGBHIP_ANALYZE_THREADS overrides.
+int analyze_threads() {
+    static const int nt = [] {
+        if (const char* e = getenv("MGBHIP_ANALYZE_THREADS")) return std::max(1, atoi(e));
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::min<unsigned>(hc ? hc : 1u, 16u);
+    }();
+    return nt;
+}
+void parallel_for(int64_t count, const std::function<void(int64_t, int64_t, int)>& fn) {
+    const int nt = (count < 50000) ? 1 : analyze_threads();
+    if (nt <= 1) { fn(0, count, 0); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt);
+    for (int t = 0; t < nt; ++t) {
+        const int64_t a = count * t / nt, b = count * (t + 1) / nt;
+        th.emplace_back([&fn, a, b, t] { fn(a, b, t); });
+    }
+    for (auto& x : th) x.join();
+}
 
 struct Graph {
     int64_t n;
@@ -53,31 +82,45 @@ struct Builder {
     // ---- 1. simplicial peeling -----------------------------------------------------
     void peel(MfPlan& plan) {
         const int64_t n = g.n;
-        std::vector<int32_t> nb;
-        std::vector<char> sel(n, 0);
+        std::vector<char> sel(n, 0), simp;
         for (int round = 0; round < opt.max_peel_rounds; ++round) {
             int64_t remaining = 0;
             for (int64_t v = 0; v < n; ++v) remaining += !removed[v];
             if (remaining == 0) break;
             std::vector<int32_t> chosen;
             std::fill(sel.begin(), sel.end(), 0);
+            // (a) which remaining nodes are simplicial (few neighbours, forming a clique): independent per node, threaded;
+            // (b) the greedy independent selection in index order, serial -- together exactly the one-pass rule
+            //     "not next to a selected node, at most peel_max_degree neighbours, neighbours form a clique".
+            simp.assign((size_t)n, 0);
+            parallel_for(n, [&](int64_t v0, int64_t v1, int) {
+                std::vector<int32_t> nbl;
+                for (int64_t v = v0; v < v1; ++v) {
+                    if (removed[v]) continue;
+                    nbl.clear();
+                    bool many = false;
+                    for (int32_t e = g.ptr[v]; e < g.ptr[v + 1]; ++e) {
+                        const int32_t u = g.idx[e];
+                        if (u == v || removed[u]) continue;
+                        nbl.push_back(u);
+                        if ((int32_t)nbl.size() > opt.peel_max_degree) { many = true; break; }
+                    }
+                    if (many) continue;
+                    bool clique = true;
+                    for (size_t a = 0; a < nbl.size() && clique; ++a)
+                        for (size_t b = a + 1; b < nbl.size(); ++b)
+                            if (!g.adjacent(nbl[a], nbl[b])) { clique = false; break; }
+                    simp[(size_t)v] = clique ? 1 : 0;
+                }
+            });
             for (int32_t v = 0; v < n; ++v) {
-                if (removed[v]) continue;
-                nb.clear();
+                if (removed[v] || !simp[(size_t)v]) continue;
                 bool blocked = false;
                 for (int32_t e = g.ptr[v]; e < g.ptr[v + 1]; ++e) {
-                    int32_t u = g.idx[e];
-                    if (u == v || removed[u]) continue;
-                    if (sel[u]) { blocked = true; break; }
-                    nb.push_back(u);
-                    if ((int32_t)nb.size() > opt.peel_max_degree) { blocked = true; break; }
+                    const int32_t u = g.idx[e];
+                    if (u != v && !removed[u] && sel[u]) { blocked = true; break; }
                 }
                 if (blocked) continue;
-                bool clique = true;
-                for (size_t a = 0; a < nb.size() && clique; ++a)
-                    for (size_t b = a + 1; b < nb.size(); ++b)
-                        if (!g.adjacent(nb[a], nb[b])) { clique = false; break; }
-                if (!clique) continue;
                 sel[v] = 1;
                 chosen.push_back(v);
             }
@@ -95,7 +138,10 @@ struct Builder {
                 }
                 return h;
             };
-            for (int32_t v : chosen) keyed.emplace_back(nbhash(v), v);
+            keyed.resize(chosen.size());
+            parallel_for((int64_t)chosen.size(), [&](int64_t i0, int64_t i1, int) {
+                for (int64_t i = i0; i < i1; ++i) keyed[(size_t)i] = {nbhash(chosen[(size_t)i]), chosen[(size_t)i]};
+            });
             std::sort(keyed.begin(), keyed.end());
             auto same_nb = [&](int32_t a, int32_t b) {
                 int32_t ea = g.ptr[a], eb = g.ptr[b];
@@ -288,6 +334,15 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
     plan.n = n;
     if (n == 0) { plan.level_ptr.assign(1, 0); return; }
     if (n > INT32_MAX) throw std::runtime_error("mf_analyze: n exceeds 32-bit indexing");
+    // MGBHIP_DEBUG >= 3: wall-clock of the phases (development aid for the time-to-first-solution breakdown)
+    const bool phase_timing = [] { const char* e = getenv("MGBHIP_DEBUG"); return e && atoi(e) >= 3; }();
+    auto t_prev = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (!phase_timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mgbhip] analysis n=%lld %-28s %.3f s\n", (long long)n, name, std::chrono::duration<double>(t - t_prev).count());
+        t_prev = t;
+    };
     Builder b{Graph{n, rowptr, colidx}, opt};
     b.pos.assign(n, -1);
     b.sn_of.assign(n, -1);
@@ -302,7 +357,9 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
         if (v < 0 || v >= n || b.removed[v]) throw std::runtime_error("mf_analyze: bad interface list");
         b.removed[v] = 1;
     }
+    phase("init");
     b.peel(plan);
+    phase("peel");
     // supernodes [0, nsn_peeled) are the element-local unknowns (round 1: the broken slacks, round 2: the element-
     // interior nodes they expose); later rounds peel ordinary mesh nodes
     const int32_t nsn_peeled = b.sn_round2_end;
@@ -312,6 +369,7 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
             if (!b.removed[v]) rest.push_back(v);
         b.dissect(rest);
     }
+    phase("dissect");
     int32_t top_sn = -1;
     if (opt.ntop > 0) {                                 // ... and eliminated last, as one supernode
         top_sn = (int32_t)b.sn_piv.size();
@@ -347,6 +405,7 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
         }
     }
 
+    phase("symbolic structure");
     // ---- exact-fit amalgamation of a child into its parent ------------------------------
     std::vector<int32_t> merged_into(nsn, -1);
     {
@@ -390,6 +449,7 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
         }
     }
 
+    phase("amalgamation");
     // ---- border unknown (MfOptions::border): last in the order, in every front's boundary, own root front ----
     std::vector<int32_t> pos_ext;
     int32_t nsn_all = nsn;
@@ -469,66 +529,116 @@ void mf_analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, const M
     for (int32_t i = 0; i < nf; ++i) plan.level_ptr[plan.fronts[i].level + 1]++;
     for (int32_t l = 0; l <= maxlevel; ++l) plan.level_ptr[l + 1] += plan.level_ptr[l];
 
+    phase("levels, numbering, index lists");
     // ---- relative indices + A scatter lists ------------------------------------------------
-    std::vector<int32_t> loc(n + 1, -1);
+    // Two passes so that the fronts can be filled by several host threads: (1) sizes -- a front owns, per pivot v, the
+    // entries {v, u} with u == v or u eliminated later (+ the border entry) -- and offsets; (2) the lists themselves,
+    // every front into its own range (the serial loop appended them in the same order: identical arrays).
     // rel: positions of a front's boundary inside its parent's index list
     for (int32_t i = 0; i < nf; ++i) {
         Front& f = plan.fronts[i];
         f.rel_off = (int64_t)plan.rel.size();
         plan.rel.resize(plan.rel.size() + (size_t)(f.m - f.k), -1);
     }
-    for (int32_t i = 0; i < nf; ++i) {
-        Front& f = plan.fronts[i];
-        const int32_t* idx = plan.front_idx.data() + f.idx_off;
-        for (int32_t j = 0; j < f.m; ++j) loc[idx[j]] = j;
-        // children of i
-        for (int32_t c = 0; c < f.nchild; ++c) {
-            Front& ch = plan.fronts[plan.children[f.child_off + c]];
-            const int32_t* cidx = plan.front_idx.data() + ch.idx_off + ch.k;
-            for (int32_t j = 0; j < ch.m - ch.k; ++j) {
-                int32_t p = loc[cidx[j]];
-                if (p < 0) throw std::runtime_error("mf_analyze: child boundary not contained in parent front");
-                plan.rel[ch.rel_off + j] = p;
-            }
-        }
-        // A entries owned by this front: pairs {v,u}, v a pivot, u == v or eliminated later
-        f.a_off = (int64_t)plan.a_src.size();
-        f.acol_off = (int64_t)plan.a_colptr.size();
-        for (int32_t lv = 0; lv < f.k; ++lv) {
-            plan.a_colptr.push_back((int32_t)((int64_t)plan.a_src.size() - f.a_off));
-            int32_t v = idx[lv];
-            if (v == n) {                       // the border's own 1 x 1 front: entry (n, n)
-                plan.a_src.push_back((int32_t)(nnz_h + n));
-                plan.a_dst.push_back(lv + lv * f.m);
-                continue;
-            }
-            for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
-                int32_t u = colidx[e];
-                if (u != v && posx[u] < posx[v]) continue;
-                int32_t lu = loc[u];
-                if (lu < 0 || lu < lv) throw std::runtime_error("mf_analyze: structure violation in A scatter");
-                int32_t src = e;
-                if (u < v) {   // symmetric(H) reads the upper triangle: entry (u, v) in row u
-                    const int32_t* lo = colidx + rowptr[u];
-                    const int32_t* hi = colidx + rowptr[u + 1];
-                    const int32_t* it = std::lower_bound(lo, hi, v);
-                    if (it == hi || *it != v) throw std::runtime_error("mf_analyze: pattern is not symmetric");
-                    src = (int32_t)(it - colidx);
+    std::vector<int64_t> a_count((size_t)nf + 1, 0);
+    parallel_for(nf, [&](int64_t i0, int64_t i1, int) {
+        for (int64_t i = i0; i < i1; ++i) {
+            const Front& f = plan.fronts[(size_t)i];
+            const int32_t* idx = plan.front_idx.data() + f.idx_off;
+            int64_t cnt = 0;
+            for (int32_t lv = 0; lv < f.k; ++lv) {
+                const int32_t v = idx[lv];
+                if (v == n) { ++cnt; continue; }
+                for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+                    const int32_t u = colidx[e];
+                    if (u != v && posx[u] < posx[v]) continue;
+                    ++cnt;
                 }
-                plan.a_src.push_back(src);
-                plan.a_dst.push_back(lu + lv * f.m);
+                if (opt.border) ++cnt;
             }
-            if (opt.border) {                   // border column entry (n, v): last row of the front
-                if (loc[n] != f.m - 1) throw std::runtime_error("mf_analyze: border is not the last row of a front");
-                if (nnz_h + n >= (int64_t)INT32_MAX) throw std::runtime_error("mf_analyze: bordered value index exceeds 32 bits");
-                plan.a_src.push_back((int32_t)(nnz_h + v));
-                plan.a_dst.push_back((f.m - 1) + lv * f.m);
-            }
+            a_count[(size_t)i + 1] = cnt;
         }
-        f.a_cnt = (int32_t)((int64_t)plan.a_src.size() - f.a_off);
-        plan.a_colptr.push_back(f.a_cnt);
-        for (int32_t j = 0; j < f.m; ++j) loc[idx[j]] = -1;
+    });
+    {
+        int64_t acol = 0;
+        for (int32_t i = 0; i < nf; ++i) {
+            Front& f = plan.fronts[i];
+            f.a_off = a_count[i];
+            f.a_cnt = (int32_t)a_count[(size_t)i + 1];
+            a_count[(size_t)i + 1] += a_count[i];
+            f.acol_off = acol;
+            acol += f.k + 1;
+        }
+        plan.a_src.assign((size_t)a_count[nf], 0);
+        plan.a_dst.assign((size_t)a_count[nf], 0);
+        plan.a_colptr.assign((size_t)acol, 0);
     }
+    if (nnz_h + n >= (int64_t)INT32_MAX && opt.border) throw std::runtime_error("mf_analyze: bordered value index exceeds 32 bits");
+    std::vector<std::string> errors((size_t)analyze_threads() + 1);
+    parallel_for(nf, [&](int64_t i0, int64_t i1, int tix) {
+        std::vector<int32_t> loc((size_t)n + 1, -1);
+        try {
+            for (int64_t i = i0; i < i1; ++i) {
+                Front& f = plan.fronts[(size_t)i];
+                const int32_t* idx = plan.front_idx.data() + f.idx_off;
+                for (int32_t j = 0; j < f.m; ++j) loc[idx[j]] = j;
+                // children of i
+                for (int32_t c = 0; c < f.nchild; ++c) {
+                    const Front& ch = plan.fronts[plan.children[f.child_off + c]];
+                    const int32_t* cidx = plan.front_idx.data() + ch.idx_off + ch.k;
+                    for (int32_t j = 0; j < ch.m - ch.k; ++j) {
+                        const int32_t p = loc[cidx[j]];
+                        if (p < 0) throw std::runtime_error("mf_analyze: child boundary not contained in parent front");
+                        plan.rel[ch.rel_off + j] = p;
+                    }
+                }
+                // A entries owned by this front: pairs {v,u}, v a pivot, u == v or eliminated later
+                int64_t w = f.a_off;
+                int32_t* cp = plan.a_colptr.data() + f.acol_off;
+                for (int32_t lv = 0; lv < f.k; ++lv) {
+                    cp[lv] = (int32_t)(w - f.a_off);
+                    const int32_t v = idx[lv];
+                    if (v == n) {                       // the border's own 1 x 1 front: entry (n, n)
+                        plan.a_src[(size_t)w] = (int32_t)(nnz_h + n);
+                        plan.a_dst[(size_t)w] = lv + lv * f.m;
+                        ++w;
+                        continue;
+                    }
+                    for (int32_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+                        const int32_t u = colidx[e];
+                        if (u != v && posx[u] < posx[v]) continue;
+                        const int32_t lu = loc[u];
+                        if (lu < 0 || lu < lv) throw std::runtime_error("mf_analyze: structure violation in A scatter");
+                        int32_t src = e;
+                        if (u < v) {   // symmetric(H) reads the upper triangle: entry (u, v) in row u
+                            const int32_t* lo = colidx + rowptr[u];
+                            const int32_t* hi = colidx + rowptr[u + 1];
+                            const int32_t* it = std::lower_bound(lo, hi, v);
+                            if (it == hi || *it != v) throw std::runtime_error("mf_analyze: pattern is not symmetric");
+                            src = (int32_t)(it - colidx);
+                        }
+                        plan.a_src[(size_t)w] = src;
+                        plan.a_dst[(size_t)w] = lu + lv * f.m;
+                        ++w;
+                    }
+                    if (opt.border) {                   // border column entry (n, v): last row of the front
+                        if (loc[n] != f.m - 1) throw std::runtime_error("mf_analyze: border is not the last row of a front");
+                        plan.a_src[(size_t)w] = (int32_t)(nnz_h + v);
+                        plan.a_dst[(size_t)w] = (f.m - 1) + lv * f.m;
+                        ++w;
+                    }
+                }
+                cp[f.k] = f.a_cnt;
+                if (w - f.a_off != f.a_cnt) throw std::runtime_error("mf_analyze: A list size mismatch");
+                for (int32_t j = 0; j < f.m; ++j) loc[idx[j]] = -1;
+            }
+        } catch (const std::exception& e) {
+            errors[(size_t)tix] = e.what();
+        }
+    });
+    for (const auto& e : errors)
+        if (!e.empty()) throw std::runtime_error(e);
+    phase("relative indices, A lists");
 }
 
 }  // namespace mgbhip

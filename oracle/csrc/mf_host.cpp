@@ -225,3 +225,35 @@ extern "C" int64_t mf_host_plan_fronts(void* h, int32_t* out4, int64_t cap) {
     }
     return nf;
 }
+
+
+// Hash of every array of the plan the product's symbolic analysis produces for a pattern (tests: the threaded parts of
+// the analysis must reproduce the serial plan exactly; MGBHIP_ANALYZE_THREADS selects the thread count per process).
+extern "C" uint64_t mf_host_plan_hash(int64_t n, const int32_t* rowptr, const int32_t* colidx, int32_t border) {
+    MfPlan plan;
+    MfOptions opt;
+    opt.border = border != 0;
+    opt.protect_peeled = true;
+    try {
+        mf_analyze(n, rowptr, colidx, opt, plan);
+    } catch (const std::exception&) {
+        return 0;
+    }
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const void* p, size_t bytes) {
+        const unsigned char* c = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    };
+    for (const Front& f : plan.fronts) {
+        const int64_t v[] = {f.k, f.m, f.level, f.parent, f.nchild, f.a_cnt, f.F_off, f.idx_off, f.u_off, f.child_off, f.rel_off, f.a_off, f.acol_off};
+        mix(v, sizeof(v));
+    }
+    mix(plan.front_idx.data(), plan.front_idx.size() * sizeof(int32_t));
+    mix(plan.children.data(), plan.children.size() * sizeof(int32_t));
+    mix(plan.rel.data(), plan.rel.size() * sizeof(int32_t));
+    mix(plan.a_src.data(), plan.a_src.size() * sizeof(int32_t));
+    mix(plan.a_dst.data(), plan.a_dst.size() * sizeof(int32_t));
+    mix(plan.a_colptr.data(), plan.a_colptr.size() * sizeof(int32_t));
+    mix(plan.level_ptr.data(), plan.level_ptr.size() * sizeof(plan.level_ptr[0]));
+    return h ? h : 1;
+}
