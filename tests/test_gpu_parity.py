@@ -778,3 +778,15 @@ def test_generic_solves_and_newton_solves_share_one_factorization_plan():
         assert np.array_equal(again["SOL_main"]["its"], sol.SOL_main["its"])
     finally:
         sol.device.close()
+
+
+def test_fused_selection_prolongation_is_bitwise_the_prolongation_launch(monkeypatch):
+    """On selection levels the element kernels gather s through the column map of R instead of a prolongation launch
+    (kernels.hip: z_at, problem.cpp: Level::Rsel): same arithmetic, so the whole solve is bit for bit the one with
+    MGBHIP_NO_FUSED_PROLONG=1 (the switch is read when a problem is uploaded)."""
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 4)), p=1.5)
+    a = m.mgb_solve(prob)
+    monkeypatch.setenv("MGBHIP_NO_FUSED_PROLONG", "1")
+    b = m.mgb_solve(prob)
+    assert np.array_equal(a.z, b.z)
+    assert np.array_equal(a.SOL_main["its"], b.SOL_main["its"])
