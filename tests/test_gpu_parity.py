@@ -11,7 +11,7 @@ import pytest
 import scipy.sparse as sp
 
 import mgb_amd as m
-from helpers import build_case, gold_z, lower_bound_problem, stacked
+from helpers import assert_z_close, build_case, gold_z, lower_bound_problem, stacked
 from oracle import mgb_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -169,7 +169,8 @@ def test_mgb_solve_matches_oracle_end_to_end(L, p):
     prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), L)), p=p)
     sol = m.mgb_solve(prob)
     so = O.mgb_solve(prob)
-    assert np.abs(sol.z - so["z"]).max() < 1e-8          # the reference's CPU-vs-CUDA bar (test/test_cuda.jl:51)
+    assert_z_close(sol.z, so["z"], f"fem2d_P2 L={L} p={p}")
+    _same_iteration_counts(sol.SOL_main["its"], so["SOL_main"]["its"])
 
 
 def test_illinois_line_search_and_exact_stopping():
@@ -177,7 +178,7 @@ def test_illinois_line_search_and_exact_stopping():
     sol = m.mgb_solve(prob, line_search=("illinois", 0.5), stopping_criterion=("exact", 0.1), finalize=False, tol=1e-6)
     so = O.mgb_solve(prob, line_search=O.linesearch_illinois(), stopping_criterion=O.stopping_exact(0.1),
                      finalize=False, tol=1e-6)
-    assert np.abs(sol.z - so["z"]).max() < 1e-6
+    assert_z_close(sol.z, so["z"], "fem1d illinois line search + exact stopping")
 
 
 def test_feasibility_phase_on_device():
@@ -208,14 +209,14 @@ def test_phase1_then_main_matches_oracle():
     so = O.mgb_solve(prob)
     assert sol.SOL_feasibility is not None and so["SOL_feasibility"] is not None
     assert abs(sol.SOL_main["ts"][0] - so["SOL_main"]["ts"][0]) <= 1e-8 * so["SOL_main"]["ts"][0]   # _matched_t
-    assert np.abs(sol.z - so["z"]).max() < 1e-6
+    assert_z_close(sol.z, so["z"], "fem2d_P2 L=2 phase I + _matched_t + main")
 
 
 def test_fem3d_p4_config4_family_matches_oracle():
     prob = m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 3)), p=4.0)
     sol = m.mgb_solve(prob)
     so = O.mgb_solve(prob)
-    assert np.abs(sol.z - so["z"]).max() < 1e-6
+    assert_z_close(sol.z, so["z"], "fem3d L=3 p=4 (config 4 family)")
 
 
 @pytest.mark.parametrize("n,p", [(10, 1.5), (12, 1.0)])
@@ -227,7 +228,7 @@ def test_spectral2d_dense_path_config5_family_matches_oracle(n, p):
     so = O.mgb_solve(prob)
     # the last finalize iteration is decided by a roundoff-level decrement: allow one step either way
     assert abs(int(sol.SOL_main["its"].sum()) - int(so["SOL_main"]["its"].sum())) <= 2
-    assert np.abs(sol.z - so["z"]).max() < 1e-8
+    assert_z_close(sol.z, so["z"], f"spectral2d n={n} p={p} dense path")
 
 
 def test_spectral2d_two_sided_obstacle_config5_matches_oracle():
@@ -240,7 +241,7 @@ def test_spectral2d_two_sided_obstacle_config5_matches_oracle():
     prob = m.assemble(mg, Q=Q, f_grid=np.tile([2.0, 0, 0, 0.5], (nn, 1)), g_grid=np.tile([0.0, 10.0], (nn, 1)))
     sol = m.mgb_solve(prob)
     so = O.mgb_solve(prob)
-    assert np.abs(sol.z - so["z"]).max() < 1e-7
+    assert_z_close(sol.z, so["z"], "spectral2d n=12 two-sided obstacle (config 5 family)")
     assert sol.z[:, 0].min() > -0.1 and sol.z[:, 0].max() < 1.0          # the obstacle is respected
 
 
@@ -261,7 +262,7 @@ def test_parabolic_solve_matches_oracle_on_a_refined_mesh():
     sol = m.parabolic_solve(mg, **kw)
     so = m.parabolic_solve(mg, solver=O.mgb_solve, **kw)
     assert len(sol.u) == 3
-    assert np.abs(np.stack(sol.u) - np.stack(so.u)).max() < 1e-6
+    assert_z_close(np.stack(sol.u), np.stack(so.u), "parabolic fem2d_P2 L=3, three time steps")
 
 
 def _full_size_properties(prob, scale, check_solve=True):
@@ -488,7 +489,7 @@ def test_ep_general_A_b_and_per_node_p_match_oracle(kind):
     # end to end, same problem: device vs oracle (reference cross-backend bar, test/test_cuda.jl:51)
     sol = m.mgb_solve(prob)
     ref = O.mgb_solve(prob)
-    assert np.abs(sol.z - ref["z"]).max() < 1e-8
+    assert_z_close(sol.z, ref["z"], f"general EP A(x), b(x), p(x) on {kind}")
     _same_iteration_counts(sol.SOL_main["its"], ref["SOL_main"]["its"])
 
 
@@ -551,7 +552,7 @@ def test_piecewise_select_mask_matches_oracle(with_gap):
     if not with_gap:     # with a gap the slack is unbounded below there: no central path (reference semantics)
         sol = m.mgb_solve(prob)
         ref = O.mgb_solve(prob)
-        assert np.abs(sol.z - ref["z"]).max() < 1e-8
+        assert_z_close(sol.z, ref["z"], "piecewise select mask")
         _same_iteration_counts(sol.SOL_main["its"], ref["SOL_main"]["its"])
 
 
@@ -632,7 +633,7 @@ def test_user_stopping_criterion_and_early_stop_callables():
     assert calls["stop"] > 50 and np.array_equal(sol.z, base.z)
     assert np.array_equal(sol.SOL_main["its"], base.SOL_main["its"])
     ref = O.mgb_solve(prob, stopping_criterion=my_stop)
-    assert np.abs(sol.z - ref["z"]).max() < 1e-8
+    assert_z_close(sol.z, ref["z"], "user stopping_criterion callable")
     # early_stop(z): leave the t-ramp once the slack component drops below 1 everywhere
     s_of = lambda z: z[n:2 * n]
 
@@ -644,7 +645,8 @@ def test_user_stopping_criterion_and_early_stop_callables():
     assert calls["early"] >= 2
     assert sol_e.SOL_main["ts"][-1] < base.SOL_main["ts"][-1]            # stopped before 1/tol
     assert np.allclose(sol_e.SOL_main["ts"], ref_e["SOL_main"]["ts"])
-    assert np.abs(sol_e.z - ref_e["z"]).max() < 1e-8 and s_of(stacked(sol_e.z)).max() < 8.0
+    assert_z_close(sol_e.z, ref_e["z"], "user early_stop callable")
+    assert s_of(stacked(sol_e.z)).max() < 8.0
 
 
 def test_custom_line_search_closure_runs_on_device_vectors():
@@ -676,11 +678,11 @@ def test_custom_line_search_closure_runs_on_device_vectors():
     base = m.mgb_solve(prob)
     sol = m.mgb_solve(prob, line_search=my_backtracking)
     assert calls["n"] > 50
-    assert np.abs(sol.z - base.z).max() < 1e-9
+    assert_z_close(sol.z, base.z, "custom line_search closure vs the resident ramp")
     a, b = np.asarray(sol.SOL_main["its"]), np.asarray(base.SOL_main["its"])
     assert a.shape == b.shape and np.abs(a - b).max() <= 1            # generic solve path (forward + backward sweeps) vs the bordered one
     ref = O.mgb_solve(prob)
-    assert np.abs(sol.z - ref["z"]).max() < 1e-8
+    assert_z_close(sol.z, ref["z"], "custom line_search closure (generic loops on device vectors)")
 
 
 # the nine CPU-vs-device cases of the reference's CUDA extension test (test/test_cuda.jl:34-56); fem2d_P1 is
@@ -702,7 +704,7 @@ def test_reference_cuda_extension_cases_device_vs_cpu(name):
     prob = CUDA_EXT_CASES[name]()
     sol = m.mgb_solve(prob)
     ref = O.mgb_solve(prob)
-    assert np.abs(sol.z - ref["z"]).max() < 1e-8                        # the reference's criterion (test/test_cuda.jl:51)
+    assert_z_close(sol.z, ref["z"], f"test_cuda.jl case {name}")     # the reference's own criterion: 1e-8 absolute (test/test_cuda.jl:51)
     assert "mgb_solve: device = HIPDevice" in sol.log
 
 
@@ -714,7 +716,7 @@ def test_config0_fem1d_p2_L6_device_vs_oracle():
         assert prob.M[0].w.size == 64 and prob.M[0].R_fine[-1].shape[1] == 95
         sol = m.mgb_solve(prob)
         ref = O.mgb_solve(prob)
-        assert np.abs(sol.z - ref["z"]).max() < 1e-8
+        assert_z_close(sol.z, ref["z"], "config 0 fem1d p=2 L=6")
         _same_iteration_counts(sol.SOL_main["its"], ref["SOL_main"]["its"])
 
 

@@ -161,3 +161,24 @@ def test_config0_fem1d_p2_L6_oracle_properties():
     order = np.argsort(x, kind="stable")
     dev = (z[:, 0] - x)[order]
     assert np.abs(dev - dev[::-1]).max() < 1e-6
+
+
+def test_hand_written_setup_equals_the_setup_layer_and_reproduces_the_golden(golden):
+    """A problem typed out as literals (tests/helpers.py: literal_fem1d_problem) from the reference's definitions: (i) the
+    package's setup layer produces exactly these arrays, (ii) the oracle on the literals reproduces the reference's golden
+    vector (test/runtests.jl:13-16).  The GPU twin is tests/test_gpu_literal_setup.py."""
+    from helpers import literal_fem1d_problem
+    lit = literal_fem1d_problem((-1.0, 0.0, 1.0), 1.0)
+    pkg = m.assemble(m.amg(m.fem1d(nodes=np.linspace(-1, 1, 3))), p=1.0)
+    for k in (0, 1):
+        assert len(lit.M[k].R_fine) == len(pkg.M[k].R_fine)
+        for a, b in zip(lit.M[k].R_fine, pkg.M[k].R_fine):
+            assert a.shape == b.shape and abs(a - b).max() == 0
+        assert lit.M[k].D_spec == pkg.M[k].D_spec
+        assert np.array_equal(lit.M[k].w, pkg.M[k].w)
+    for name in ("id", "dx"):
+        assert np.array_equal(lit.geometry.operators[name].data, pkg.geometry.operators[name].data)
+    assert np.array_equal(lit.f, pkg.f) and np.array_equal(lit.g, pkg.g)
+    case = golden["fem1d_3nodes_p1"]
+    z = O.mgb_solve(lit)["z"]
+    assert np.linalg.norm(z - np.array(case["z_colmajor"]).reshape(case["ncols"], -1).T) < case["tol"]
