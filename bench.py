@@ -82,21 +82,34 @@ def cpu_baseline(prob, budget_s):
                 seconds=el, solve_seconds=st.get("solve_s", 0.0))
 
 
-def measure_traffic(L, p, rs_kwargs):
-    """HBM bytes of one fine-level f2 launch from rocprofv3 PMC counters, measured live: two child
-    processes (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md), started before this
-    process touches the GPU, each running tools/gpu_kernels.py (3 evaluations of f0/f1/f2 + assembly at the
-    fine level of the same workload).  FETCH_SIZE is doubled for wide coalesced reads on gfx950 and both
-    counters are in KiB, as that guide prescribes.  Returns (bytes or None, note)."""
+def profile_children(L, p, rs_kwargs):
+    """rocprofv3 child processes, started before this process touches the GPU, each running tools/gpu_kernels.py (the
+    Newton loop's own fine-level sequence through mgbhip_newton_direction, 1 assembled + 3 condensed factorizations):
+      * two --pmc passes (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md; FETCH_SIZE doubled for wide
+        coalesced reads on gfx950, both in KiB) -> HBM bytes of one condensing f2 launch;
+      * one --kernel-trace --stats pass -> average device duration of every kernel (the f2 roofline and the solver's
+        roofline are computed from these, not from hipEvents).
+    Returns (f2 bytes or None, note, {kernel name: (calls, avg_ns, total_ns)} or None)."""
     import csv, glob, shutil, subprocess, tempfile
     if shutil.which("rocprofv3") is None:
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", None
+    child = [sys.executable, os.path.join(HERE, "tools", "gpu_kernels.py"), str(L), str(p), "3", json.dumps(rs_kwargs)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    kstats, knote = None, ""
+    d = tempfile.mkdtemp(prefix="mgb_kt_", dir="/tmp")
+    try:
+        subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp",
+                       env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+        f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+        kstats = {r["Name"]: (int(r["Calls"]), float(r["AverageNs"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(f))}
+    except Exception as e:          # profiler unavailable / refused: report, never guess
+        knote = f"kernel-trace pass failed: {type(e).__name__}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="mgb_pmc_", dir="/tmp")
-        env = dict(os.environ, TMPDIR="/tmp")
-        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-               sys.executable, os.path.join(HERE, "tools", "gpu_kernels.py"), str(L), str(p), "3", json.dumps(rs_kwargs)]
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
@@ -106,13 +119,72 @@ def measure_traffic(L, p, rs_kwargs):
                 if r.get("Counter_Name") == counter and "elem_f2_fast" in r["Kernel_Name"] and ("true" in r["Kernel_Name"] or "(bool)1" in r["Kernel_Name"]):
                     tot += float(r["Counter_Value"]); cnt += 1
             if cnt == 0:
-                return None, f"no elem_f2_fast rows in the {counter} pass"
+                return None, f"no elem_f2_fast rows in the {counter} pass", kstats
             vals[counter] = tot / cnt
-        except Exception as e:      # profiler unavailable / refused: report, never guess
-            return None, f"{counter} pass failed: {type(e).__name__}"
+        except Exception as e:
+            return None, f"{counter} pass failed: {type(e).__name__} {knote}", kstats
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return 1024.0 * (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (KiB; FETCH doubled on gfx950)"
+    return (1024.0 * (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]),
+            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (KiB; FETCH doubled on gfx950) " + knote, kstats)
+
+
+FP64_MFMA_PEAK_TFLOPS = 78.6       # MI355X dense fp64 matrix peak (spec); tools/micro/mfma_f64_peak.hip sustains 49
+
+
+def _kernel_group(kstats, prefixes, condensing=None):
+    """(calls, total_ns, {short name: (calls, avg_us)}) of the kernels whose demangled name contains one of `prefixes`."""
+    calls, total, detail = 0, 0.0, {}
+    for name, (c, avg, tot) in (kstats or {}).items():
+        for pre in prefixes:
+            if pre in name:
+                calls += c; total += tot
+                key = pre + ("<...>" if "<" in name.split(pre, 1)[1][:2] else "")
+                pc, pt = detail.get(key, (0, 0.0))
+                detail[key] = (pc + c, pt + tot)
+                break
+    return calls, total, {k: dict(calls=c, avg_us=t / c / 1e3) for k, (c, t) in detail.items() if c}
+
+
+FACTOR_KERNELS = ("mf_big_step", "mf_big_gather", "mf_big_schur", "mf_big_diag0", "mf_big_assemble", "mf_big_panel", "mf_big_update",
+                  "mf_factor_small", "mf_factor_wave", "mf_factor_tiny", "border_tail_kernel")
+BACKWARD_KERNELS = ("mf_bwd_inv", "mf_backward_small", "mf_backward_tiny", "mf_bwd_big")
+
+
+def solver_roofline(kstats, chain, stats, hipevent_factor_us, hipevent_trisolve_us, factorizations_in_child=4):
+    """`roofline_solver`: what bounds the sparse LDL' that takes most of a Newton iteration.  Neither HBM nor the matrix
+    cores: the fraction of each is reported from the rocprofv3 kernel durations of the child pass, next to the latency
+    chain that does bound it (sequential 32-column pivot blocks of the large fronts x device time per block)."""
+    arena_bytes = 8.0 * chain["arena_doubles"]
+    floor_bytes = 2.0 * arena_bytes                    # every frontal entry written once (assembly) and read once (update / parent)
+    out = dict(bound="latency (pivot chain): neither hbm nor mfma",
+               arena_bytes=arena_bytes, algorithmic_bytes=floor_bytes,
+               algorithmic_bytes_note="2 x arena: every front is formed once and consumed once; the trailing updates of the "
+                                      "32-column steps re-read and re-write part of it (extra_trailing_bytes)",
+               extra_trailing_bytes=8.0 * chain["extra_trailing_doubles"],
+               factor_flops=chain["factor_flops"], pivot_blocks_on_critical_path=chain["pivot_blocks_on_critical_path"],
+               large_front_tree_levels=chain["large_front_tree_levels"], launches_per_factorization=chain["launches_per_factorization"],
+               launches_per_backward_sweep=chain["launches_per_backward_sweep"], tree_levels=stats["tree_levels"],
+               hipevent_factor_avg_us_all_levels=hipevent_factor_us, hipevent_trisolve_avg_us_all_levels=hipevent_trisolve_us)
+    if kstats:
+        fc, ft, fd = _kernel_group(kstats, FACTOR_KERNELS)
+        bc, bt, bd = _kernel_group(kstats, BACKWARD_KERNELS)
+        fac_us = ft / 1e3 / factorizations_in_child
+        bwd_us = bt / 1e3 / factorizations_in_child
+        step = fd.get("mf_big_step", {}).get("avg_us", 0.0)
+        out.update(source="rocprofv3 --kernel-trace --stats child pass (tools/gpu_kernels.py: 4 fine-level Newton directions)",
+                   factor_us=fac_us, backward_us=bwd_us, kernels=dict(factor=fd, backward=bd),
+                   hbm=dict(achieved=floor_bytes / (fac_us * 1e-6) / 1e9 if fac_us else None, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=(floor_bytes / (fac_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if fac_us else None),
+                   mfma=dict(achieved=chain["factor_flops"] / (fac_us * 1e-6) / 1e12 if fac_us else None, peak=FP64_MFMA_PEAK_TFLOPS,
+                             unit="TFLOP/s", frac=(chain["factor_flops"] / (fac_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if fac_us else None),
+                   critical_path=dict(blocks=chain["pivot_blocks_on_critical_path"], mf_big_step_avg_us=step,
+                                      model_us=chain["pivot_blocks_on_critical_path"] * step,
+                                      note="device time of the step launches alone if every one of them sat on the chain; "
+                                           "the rest of factor_us is assembly (gather), the LDS-front levels and the one-pass Schur updates"))
+    else:
+        out["source"] = "kernel-trace child pass unavailable: hipEvent stage timers only"
+    return out
 
 
 def run_workload(m, DeviceMGBProblem, mgb_driver, MGBConvergenceFailure, L, p, dev_index, warmup, rank):
@@ -172,9 +244,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # PMC passes first: child processes, before this process initialises the GPU (rank 0, N = 1 only)
-    traffic, traffic_note = None, "not measured"
+    traffic, traffic_note, kstats = None, "not measured", None
     if world == 1 and rank == 0 and not args.no_traffic and os.environ.get("MGB_BENCH_TRAFFIC", "1") == "1":
-        traffic, traffic_note = measure_traffic(args.L, args.p, hierarchies(args.p, args.L)[0])
+        traffic, traffic_note, kstats = profile_children(args.L, args.p, hierarchies(args.p, args.L)[0])
 
     import torch
     if not torch.cuda.is_available():
@@ -244,7 +316,7 @@ def main():
                                         args.warmup, rank)
     if traffic is not None and used != hierarchies(args.p, args.L)[0]:
         # the PMC child passes profiled the first hierarchy variant; the timed workload fell through to another one
-        traffic, traffic_note = None, f"PMC passes ran on hierarchy {hierarchies(args.p, args.L)[0]}, the workload on {used}: not comparable"
+        traffic, traffic_note, kstats = None, f"PMC passes ran on hierarchy {hierarchies(args.p, args.L)[0]}, the workload on {used}: not comparable", None
     barrier()
     t0 = time.perf_counter()
     its_total, solve_s, core_s, last = timed_solves(mgb_driver, D, args.steps)
@@ -265,9 +337,14 @@ def main():
     st = {k: main.stage_ms(k) for k in ("f2", "assemble", "f0", "f1", "f01", "restrict", "prolong", "factor", "trisolve")}
     main.reset_stage_timers(False)
     avg_us = {k: (1e3 * ms / cnt if cnt else 0.0) for k, (ms, cnt) in st.items()}
-    f2_avg_s = avg_us["f2"] * 1e-6
     gbs = lambda nbytes, us: (nbytes / (us * 1e-6) / 1e9) if us > 0 else 0.0
-    achieved = gbs(BYTES["f2"] * n, avg_us["f2"])
+    # the roofline's launch duration: rocprofv3's kernel-trace average of the condensing f2 instantiation (child pass);
+    # the hipEvent stage timer of the live solve is kept beside it (it brackets the launch, a few us more)
+    f2_hipevent_us = avg_us["f2"]
+    f2_rocprof = [(c, a) for name, (c, a, t) in (kstats or {}).items()
+                  if "elem_f2_fast" in name and ("true" in name or "(bool)1" in name)]
+    f2_us = (sum(c * a for c, a in f2_rocprof) / sum(c for c, a in f2_rocprof) / 1e3) if f2_rocprof else f2_hipevent_us
+    achieved = gbs(BYTES["f2"] * n, f2_us)
     # aggregate of SURVEY 8(d): one fine Newton iteration = f2 + assembly + f0 + f1 (prolongation and the
     # R' gather are part of those stages' stage timers) against 1285 B / node.  The line search evaluates
     # f0 and f1 of a trial in ONE pass over the operators (stage "f01"); the separate f0 / f1 stages only
@@ -283,12 +360,14 @@ def main():
         numerator="SURVEY 8(d) algorithmic bytes of f2 alone: 347 B/node x n (the kernel also does the assembly's and the leaf "
                   "level's work, which 8(d) prices at 488 B/node more; not claimed here)",
         traffic=traffic, traffic_source=traffic_note,
-        bytes_per_launch=BYTES["f2"] * n, avg_launch_us=avg_us["f2"], launches=int(st["f2"][1]),
+        bytes_per_launch=BYTES["f2"] * n, avg_launch_us=f2_us,
+        avg_launch_source=("rocprofv3 --kernel-trace --stats child pass" if f2_rocprof else "hipEvent stage timers (no kernel trace)"),
+        avg_launch_us_hipevents=f2_hipevent_us, launches=int(st["f2"][1]),
         moved_bytes_model=F2_MOVED_BYTES_PER_NODE * n,
-        moved_gbs=gbs(F2_MOVED_BYTES_PER_NODE * n, avg_us["f2"]),
-        moved_frac=gbs(F2_MOVED_BYTES_PER_NODE * n, avg_us["f2"]) / HBM_PEAK_GBS,
-        measured_gbs=(gbs(traffic, avg_us["f2"]) if traffic else None),
-        measured_frac=(gbs(traffic, avg_us["f2"]) / HBM_PEAK_GBS if traffic else None),
+        moved_gbs=gbs(F2_MOVED_BYTES_PER_NODE * n, f2_us),
+        moved_frac=gbs(F2_MOVED_BYTES_PER_NODE * n, f2_us) / HBM_PEAK_GBS,
+        measured_gbs=(gbs(traffic, f2_us) if traffic else None),
+        measured_frac=(gbs(traffic, f2_us) / HBM_PEAK_GBS if traffic else None),
         aggregate=dict(stages_us={"f0+f1 (one pass)": trial_us, "restrict": avg_us["restrict"], "f2": avg_us["f2"],
                                   "assemble": avg_us["assemble"]}, total_us=agg_us,
                        note=("bytes are SURVEY 8(d)'s algorithmic 1285 B/node; the device moves fewer: the trial reads the operators "
@@ -299,6 +378,7 @@ def main():
         factor_avg_us=avg_us["factor"], trisolve_avg_us=avg_us["trisolve"],
         solver_note="factor carries the forward substitution (bordered LDL'); trisolve is the backward sweep only")
     stats = main.solver_stats(fine)
+    roofline_solver = solver_roofline(kstats, main.solver_chain(fine), stats, avg_us["factor"], avg_us["trisolve"])
 
     out = None
     if rank == 0:
@@ -333,6 +413,7 @@ def main():
             "setup_s": setup,
             "factorization": {k: stats[k] for k in ("fronts", "max_front", "factor_flops", "tree_levels", "nnz", "unknowns")},
             "roofline": roofline,
+            "roofline_solver": roofline_solver,
         }
     D.close()
     # ---- north_star target line: fem2d_P2 p = 1.5 at the same L (BASELINE.json north_star), rank 0 / N = 1 ----

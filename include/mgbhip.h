@@ -266,6 +266,12 @@ int mgbhip_reset_stage_timers(mgbhip_problem* prob, int enable);
  * front, [2] arena doubles, [3] factor flops, [4] peeled unknowns, [5] tree levels,
  * [6] nnz(H), [7] unknowns.                                                             */
 int mgbhip_solver_stats(mgbhip_problem* prob, int32_t level, double* out8);
+/* Shape of one factorization + backward sweep of a level as the device runs it (bench.py: roofline_solver): out[0]
+ * sequential 32-column pivot blocks on the critical path of the large fronts, [1] tree levels on the large-front
+ * path, [2] kernel launches per factorization, [3] per backward sweep, [4] arena doubles, [5] factor flops,
+ * [6] doubles the trailing updates move beyond one pass over the arena, [7] reserved.  The reference's counterpart is
+ * opaque (cuDSS FACTORIZATION + SOLVE per Newton iteration, ext/MultiGridBarrierCUDAExt/cudss_solver.jl:279-288). */
+int mgbhip_solver_chain(mgbhip_problem* prob, int32_t level, double* out8);
 
 #ifdef __cplusplus
 }

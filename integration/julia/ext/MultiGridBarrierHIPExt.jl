@@ -385,6 +385,11 @@ function hip_mgb_driver(img::HIPImage{T}, f::Matrix{T}, g::Matrix{T}, Q::Convex{
                         finalize=true, barrier_nodes=nothing, stopping_criterion=nothing, early_stop=nothing,
                         line_search=nothing, rest...) where {T}
     isempty(rest) || error("HIPDevice: unsupported keyword(s) $(keys(rest))")
+    # mgb_driver releases the image in its `finally` (mgb_cleanup nulls ctx / main / feas): a second solve on the same
+    # MGBProblem would hand C_NULL handles to libmgbhip
+    (img.ctx == C_NULL || img.main == C_NULL) &&
+        error("HIPDevice: this device image was already released by a previous solve; pass keep_image=true to " *
+              "mgb_solve to reuse it, or call native_to_device(HIPDevice, prob) again")
     # `finalize`: true / false / NoFinalize() / a stopping_exact-style closure is not representable in mgbhip_options
     # beyond on/off + theta; closures other than the default run on the device-vector path below
     generic = line_search !== nothing || !(finalize isa Bool)

@@ -210,7 +210,8 @@ int mgbhip_solve(mgbhip_problem* P, int32_t level, const double* g, double* x) {
     P->d_g.upload(g, m, st);
     P->factor(level);
     P->trisolve(level, P->d_g.p, P->d_nv.p);
-    const int status = P->levels[level].solver.status(st);
+    int status = P->levels[level].solver.status(st);
+    if (status != MGBHIP_OK && P->lu_fallback(level, P->d_g.p, P->d_nv.p)) status = MGBHIP_OK;   // LDL' failed: pivoted LU (src/utils.jl:145)
     P->d_nv.download(x, m, st);
     MGB_HIP_CHECK(hipStreamSynchronize(st));
     if (status != MGBHIP_OK) g_last_error = "Cholesky met a non-positive pivot";
@@ -243,7 +244,8 @@ int mgbhip_solve_newton(mgbhip_problem* P, int32_t level, const double* g, doubl
     P->d_g.upload(g, m, st);
     P->factor(level, P->d_g.p);                    // [H -g; -g' -1]: the forward substitution rides along
     P->trisolve_carried(level, P->d_nv.p);         // one backward sweep from x_n = 1
-    const int status = P->levels[level].solver.status(st);
+    int status = P->levels[level].solver.status(st);
+    if (status != MGBHIP_OK && P->lu_fallback(level, P->d_g.p, P->d_nv.p)) status = MGBHIP_OK;   // LDL' failed: pivoted LU (src/utils.jl:145)
     P->d_nv.download(x, m, st);
     MGB_HIP_CHECK(hipStreamSynchronize(st));
     if (lambda2) {
@@ -604,6 +606,16 @@ int mgbhip_solver_stats(mgbhip_problem* P, int32_t level, double* out) {
     out[5] = pl.level_ptr.empty() ? 0.0 : (double)(pl.level_ptr.size() - 1);
     out[6] = (double)L.nnz;
     out[7] = (double)L.m;
+    return MGBHIP_OK;
+    MGB_API_END
+}
+
+int mgbhip_solver_chain(mgbhip_problem* P, int32_t level, double* out) {
+    MGB_API_BEGIN
+    check_level(P, level);
+    MGB_REQUIRE(out != nullptr, "null argument");
+    MGB_REQUIRE(P->levels[level].solver.analyzed, "mgbhip_solver_chain: the level has not been factored yet");
+    P->levels[level].solver.chain_stats(out);
     return MGBHIP_OK;
     MGB_API_END
 }

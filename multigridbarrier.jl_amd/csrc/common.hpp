@@ -81,12 +81,17 @@ struct DevBuf {
 struct PinnedBuf {
     double* d = nullptr;        // 16 doubles
     int32_t* i = nullptr;       // 16 ints
+    double* dev = nullptr;      // the same 16 doubles as the device sees them (finishing kernels store their results here)
     PinnedBuf() {
         void* p = nullptr;
         if (hipHostMalloc(&p, 16 * sizeof(double) + 16 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
             throw HipError("hipHostMalloc failed for the scalar read-back block");
         d = static_cast<double*>(p);
         i = reinterpret_cast<int32_t*>(d + 16);
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || dp == nullptr)
+            throw HipError("hipHostGetDevicePointer failed for the scalar read-back block");
+        dev = static_cast<double*>(dp);
     }
     ~PinnedBuf() { if (d) (void)hipHostFree(d); }
     PinnedBuf(const PinnedBuf&) = delete;

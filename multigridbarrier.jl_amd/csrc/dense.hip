@@ -327,6 +327,109 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(int M, int N, int K,
             }
 }
 
+// ---- pivoted fallback of the symmetric solve -----------------------------------------------------------------------------
+// `solve(symmetric(H), g)` in the reference is Julia's `Symmetric(H) \ g`: Cholesky, then LDL', then LU when the
+// symmetric factorizations fail (src/utils.jl:142-145).  The multifrontal LDL' of mf_numeric.hip is un-pivoted (a fixed
+// elimination order is what keeps its symbolic plan); when it meets an exactly zero / non-finite pivot on a system
+// small enough to be held densely, this kernel plays the reference's last resort: dense LU with partial (row) pivoting
+// of the matrix whose upper triangle is H's, one workgroup, the matrix in a row-major global scratch.  It is a rare
+// path (a singular leading block of an otherwise regular coarse system), so it is written for determinism, not speed:
+// pivot = the first row of largest modulus (ties to the smaller index), every sum in a fixed order.
+constexpr int LU_THREADS = 1024;
+__global__ __launch_bounds__(LU_THREADS) void dense_lu_solve_kernel(int m, const int32_t* __restrict__ Hptr,
+                                                                    const int32_t* __restrict__ Hcol,
+                                                                    const double* __restrict__ Hval, double* __restrict__ A,
+                                                                    const double* __restrict__ g, double* __restrict__ x,
+                                                                    int32_t* __restrict__ status) {
+    __shared__ double rv[LU_THREADS];
+    __shared__ int ri[LU_THREADS];
+    __shared__ int piv_row;
+    __shared__ double piv_val;
+    const int tid = threadIdx.x;
+    const int64_t mm = (int64_t)m * m;
+    for (int64_t i = tid; i < mm; i += LU_THREADS) A[i] = 0.0;
+    for (int i = tid; i < m; i += LU_THREADS) x[i] = g[i];
+    __syncthreads();
+    // symmetric(H): the upper triangle of the assembled CSR, mirrored
+    for (int i = tid; i < m; i += LU_THREADS)
+        for (int32_t q = Hptr[i]; q < Hptr[i + 1]; ++q) {
+            const int j = Hcol[q];
+            if (j >= i) {
+                A[(int64_t)i * m + j] = Hval[q];
+                A[(int64_t)j * m + i] = Hval[q];      // distinct (i, j) pairs: no two threads write one entry
+            }
+        }
+    __syncthreads();
+    for (int k = 0; k < m; ++k) {
+        // pivot search in column k, rows k .. m-1
+        double best = -1.0;
+        int bi = m;
+        for (int i = k + tid; i < m; i += LU_THREADS) {
+            double v = fabs(A[(int64_t)i * m + k]);
+            if (!(v == v)) v = INFINITY;                 // a NaN entry is reported through the pivot test below
+            if (v > best) { best = v; bi = i; }
+        }
+        rv[tid] = best;
+        ri[tid] = bi;
+        __syncthreads();
+        for (int off = LU_THREADS / 2; off > 0; off >>= 1) {
+            if (tid < off) {
+                const double a = rv[tid], b = rv[tid + off];
+                if (b > a || (b == a && ri[tid + off] < ri[tid])) { rv[tid] = b; ri[tid] = ri[tid + off]; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            piv_row = ri[0];
+            piv_val = (ri[0] < m) ? A[(int64_t)ri[0] * m + k] : 0.0;
+            if (!(rv[0] > 0.0) || !isfinite(rv[0])) atomicOr(status, 1);      // singular to working precision / non-finite
+        }
+        __syncthreads();
+        const int p = piv_row;
+        const double d = piv_val;
+        if (!(fabs(d) > 0.0) || !isfinite(d)) return;                          // uniform: every thread sees the same pivot
+        if (p != k) {
+            for (int j = tid; j < m; j += LU_THREADS) {
+                const double a = A[(int64_t)k * m + j];
+                A[(int64_t)k * m + j] = A[(int64_t)p * m + j];
+                A[(int64_t)p * m + j] = a;
+            }
+            if (tid == 0) { const double a = x[k]; x[k] = x[p]; x[p] = a; }
+            __syncthreads();
+        }
+        // multipliers into column k, right-hand side
+        const double xk = x[k];
+        __syncthreads();
+        for (int i = k + 1 + tid; i < m; i += LU_THREADS) {
+            const double l = A[(int64_t)i * m + k] / d;
+            A[(int64_t)i * m + k] = l;
+            x[i] -= l * xk;
+        }
+        __syncthreads();
+        // rank-1 update of the trailing block (row-major: consecutive threads on consecutive columns)
+        const int w = m - k - 1;
+        const int64_t tot = (int64_t)w * w;
+        for (int64_t t = tid; t < tot; t += LU_THREADS) {
+            const int i = k + 1 + (int)(t / w), j = k + 1 + (int)(t % w);
+            A[(int64_t)i * m + j] -= A[(int64_t)i * m + k] * A[(int64_t)k * m + j];
+        }
+        __syncthreads();
+    }
+    // back substitution U x = y
+    for (int k = m - 1; k >= 0; --k) {
+        double s = 0.0;
+        for (int j = k + 1 + tid; j < m; j += LU_THREADS) s += A[(int64_t)k * m + j] * x[j];
+        rv[tid] = s;
+        __syncthreads();
+        for (int off = LU_THREADS / 2; off > 0; off >>= 1) {
+            if (tid < off) rv[tid] += rv[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) x[k] = (x[k] - rv[0]) / A[(int64_t)k * m + k];
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int64_t dense_grid(int64_t n) { return (n + 255) / 256; }
@@ -421,6 +524,12 @@ void launch_dense_eval(const ElemParams& P, int mode, hipStream_t st) {
             if (first) MGB_HIP_CHECK(hipMemsetAsync(ra, 0, sizeof(double) * n, st));
         }
     }
+}
+
+void launch_dense_lu_solve(int m, const int32_t* Hptr, const int32_t* Hcol, const double* Hval, double* scratch_mm, const double* g,
+                           double* x, int32_t* status, hipStream_t st) {
+    hipLaunchKernelGGL(dense_lu_solve_kernel, dim3(1), dim3(LU_THREADS), 0, st, m, Hptr, Hcol, Hval, scratch_mm, g, x, status);
+    MGB_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace mgbhip

@@ -32,5 +32,11 @@ void launch_dense_weight(int NY, int klo, int khi, int64_t n, int64_t m, int64_t
 // node-wise evaluation (same modes and outputs as launch_elem) for the dense path
 void launch_dense_eval(const ElemParams& P, int mode, hipStream_t st);
 int64_t dense_grid(int64_t n);
+// Pivoted fallback of `solve(symmetric(H), g)` for small systems (src/utils.jl:142-145: Cholesky -> LDL' -> LU): dense LU with
+// partial pivoting of the matrix whose upper triangle is the CSR H's; x = H^{-1} g; *status |= 1 when singular / non-finite.
+// scratch_mm: m*m doubles.  x must not alias g.
+constexpr int DENSE_LU_MAX_M = 2048;
+void launch_dense_lu_solve(int m, const int32_t* Hptr, const int32_t* Hcol, const double* Hval, double* scratch_mm, const double* g,
+                           double* x, int32_t* status, hipStream_t st);
 
 }  // namespace mgbhip

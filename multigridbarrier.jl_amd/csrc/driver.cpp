@@ -91,12 +91,14 @@ struct NewtonCtx {
 bool trial_values(NewtonCtx& C, double& ynext, double& gnorm_next, int32_t* moved = nullptr) {
     mgbhip_problem* P = C.P;
     hipStream_t st = P->stream();
-    P->eval_f01_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c, P->d_gn.p, P->sharded() ? P->d_gnpart.p : nullptr);
-    // value (d_scal[0]), |g|^2, non-finite count and the step kernel's "moved" flag in ONE read-back
-    launch_vec_stats(P->d_gn.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st, P->own_mask(C.level), P->d_flag.p, 1);
-    MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d, P->d_scal.p, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+    // the element kernel leaves its workgroup partials of f0; their sum, |g|^2, the non-finite count and the step kernel's
+    // "moved" stamp are finished by ONE launch that also stores them in the pinned block (no reduce / copy launches)
+    const bool fused = !P->dense;
+    P->eval_f01_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c, P->d_gn.p, P->sharded() ? P->d_gnpart.p : nullptr, fused);
+    launch_trial_finish(P->d_gn.p, C.m, P->d_scratch.p, fused ? P->d_partials.p : nullptr, elem_grid(P->p, P->N), P->d_scal.p,
+                        P->d_flag.p, P->pin.dev, st, P->own_mask(C.level));
     MGB_HIP_CHECK(hipStreamSynchronize(st));
-    P->pin.i[0] = P->pin.d[4] != 0.0 ? 1 : 0;
+    P->pin.i[0] = P->pin.d[4] == (double)P->step_stamp ? 1 : 0;      // the stamp of the step kernel that formed this trial point
     if (P->sharded()) {              // value, |g|^2, non-finite count and the "moved" flag in one sum over ranks
         P->pin.d[1] = (double)P->pin.i[0];
         P->allreduce_host(P->pin.d, 4, 0);
@@ -120,8 +122,7 @@ bool linesearch_backtracking(NewtonCtx& C, const mgbhip_options& opt, double y, 
     double s = 1.0;
     bool have = false;
     while (s > 0.0) {
-        P->d_flag.zero(st, 1);
-        launch_step(P->d_x.p, P->d_nv.p, s, P->d_xn.p, C.m, P->d_flag.p, st);
+        launch_step(P->d_x.p, P->d_nv.p, s, P->d_xn.p, C.m, P->d_flag.p, ++P->step_stamp, st);
         P->touch();
         double yn, gn;
         int32_t moved = 0;
@@ -143,8 +144,7 @@ bool linesearch_illinois(NewtonCtx& C, const mgbhip_options& opt, double inc, do
     hipStream_t st = P->stream();
     struct Reject {};
     auto phi = [&](double sigma) -> double {
-        P->d_flag.zero(st, 1);
-        launch_step(P->d_x.p, P->d_nv.p, sigma, P->d_xn.p, C.m, P->d_flag.p, st);
+        launch_step(P->d_x.p, P->d_nv.p, sigma, P->d_xn.p, C.m, P->d_flag.p, ++P->step_stamp, st);
         P->touch();
         const double f = C.F0(P->d_xn.p);
         if (!std::isfinite(f)) throw Reject();
@@ -170,8 +170,7 @@ bool linesearch_illinois(NewtonCtx& C, const mgbhip_options& opt, double inc, do
                 b = c; fb = fc;
             }
             if (!done) throw Reject();
-            P->d_flag.zero(st, 1);
-            launch_step(P->d_x.p, P->d_nv.p, root, P->d_xn.p, C.m, P->d_flag.p, st);
+            launch_step(P->d_x.p, P->d_nv.p, root, P->d_xn.p, C.m, P->d_flag.p, ++P->step_stamp, st);
         P->touch();
             double yn, gn;
             if (!trial_values(C, yn, gn)) throw Reject();
@@ -213,16 +212,19 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
         C.F2(P->d_x.p);
         auto t0 = std::chrono::steady_clock::now();
         int fstatus = MGBHIP_OK;
+        int leaf_flag = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
             P->factor(C.level, C.rhs_of_g());               // the gradient rides along: no forward sweep afterwards
             P->trisolve_carried(C.level, P->d_nv.p);
-            // pivot flag, direction statistics and lambda^2 = <g, n> in one round trip
-            launch_dir_stats(P->d_nv.p, P->d_g.p, C.m, P->d_scratch.p, P->d_scal.p + 2, st, P->own_mask(C.level),
-                             L.solver.status_flags(), 2);
-            MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+            // pivot flags, direction statistics and lambda^2 = <g, n> in one round trip: the finishing launch stores them in
+            // the pinned block and clears the solver's flags for the next factorization (no copy / memset launches)
+            launch_dir_finish(P->d_nv.p, P->d_g.p, C.m, P->d_scratch.p, P->d_scal.p, L.solver.status_flags_rw(), P->pin.dev, st,
+                              P->own_mask(C.level));
+            L.solver.flags_cleared();
             MGB_HIP_CHECK(hipStreamSynchronize(st));
             P->pin.i[1] = P->pin.d[5] != 0.0 ? 1 : 0;
-            P->pin.i[2] = P->pin.d[6] != 0.0 ? 1 : 0;
+            leaf_flag |= P->pin.d[6] != 0.0 ? 1 : 0;        // the condensed leaves are not re-formed by a refactorization: their flag sticks
+            P->pin.i[2] = leaf_flag;
             fstatus = MfSolver::status_from(P->pin.i + 1, L.solver.factored_condensed);
             if (P->sharded()) {          // every rank must take the same branch: the pivot flag travels with the sums
                 P->pin.d[5] = fstatus != MGBHIP_OK ? 1.0 : 0.0;
@@ -241,6 +243,18 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
                 C.level, k, fstatus, P->pin.d[4]);
             L.solver.robust = true;
             L.factored = false;
+        }
+        if (fstatus != MGBHIP_OK && P->lu_fallback(C.level, P->d_g.p, P->d_nv.p)) {
+            // An exactly zero / non-finite pivot ended the un-pivoted LDL' (twice: inverse-based and substitution kernels).
+            // Julia's `Symmetric(H) \ g` falls through Cholesky -> LDL' -> LU (src/utils.jl:142-145): so does this solve, with a
+            // dense partially pivoted LU on the device, for systems small enough to be held densely.  The reference's own
+            // tests (non-finite direction, lambda^2 <= 0) then see that direction.
+            DBG("newton[lev %d] k=%d: LDL' met a zero pivot; direction from the pivoted LU fallback\n", C.level, k);
+            launch_dir_finish(P->d_nv.p, P->d_g.p, C.m, P->d_scratch.p, P->d_scal.p, L.solver.status_flags_rw(), P->pin.dev, st,
+                              P->own_mask(C.level));
+            L.solver.flags_cleared();
+            MGB_HIP_CHECK(hipStreamSynchronize(st));
+            fstatus = MGBHIP_OK;
         }
         P->cnt.solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (fstatus != MGBHIP_OK) {

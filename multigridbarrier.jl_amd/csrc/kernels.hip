@@ -848,24 +848,52 @@ __global__ __launch_bounds__(256) void dir_stats_kernel(const double* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void reduce2_kernel(const double* __restrict__ partials, int nb,
-                                                      double* __restrict__ out, int nout,
-                                                      const int32_t* __restrict__ ints, int nints) {
+// Second stage of every two-stage reduction, ONE launch for everything the host wants from one synchronisation:
+// up to four strided sums (each: 256 threads stride over the partials + the same LDS tree as before, so the values
+// are bit for bit those of the separate reduce_partials / reduce2 launches this replaces), device flags that ride
+// behind the sums as doubles (a pivot status, the step kernel's "moved" stamp; `reset` clears them for their next
+// producer: no hipMemsetAsync per Newton iteration), and a copy of out[host_lo .. host_lo + host_n) straight into
+// the pinned host block (host-coherent memory: visible after the stream synchronises; no copy launch).
+struct FinishJob { const double* src; int64_t count; int32_t out; };
+struct FinishParams {
+    FinishJob job[4];
+    int32_t njobs;
+    double* out;
+    int32_t* ints;
+    int32_t nints, ints_out, reset;
+    double* host;
+    int32_t host_lo, host_n;
+};
+__global__ __launch_bounds__(256) void finish_kernel(const FinishParams P) {
     __shared__ double red[256];
+    __shared__ double res[16];
     const int tid = threadIdx.x;
-    // device flags the host wants in the same read-back (a pivot status, a "moved" flag) ride behind the sums as doubles
-    if (tid < nints) out[nout + tid] = (double)ints[tid];
-    for (int o = 0; o < nout; ++o) {
+    if (tid < P.nints) {
+        res[P.ints_out + tid] = (double)P.ints[tid];
+        if (P.reset) P.ints[tid] = 0;
+    }
+    for (int o = 0; o < P.njobs; ++o) {
+        const double* __restrict__ src = P.job[o].src;
+        const int64_t cnt = P.job[o].count;
         double s = 0.0;
-        for (int i = tid; i < nb; i += 256) s += partials[o * nb + i];
+        for (int64_t i = tid; i < cnt; i += 256) s += src[i];
         red[tid] = s;
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) {
             if (tid < off) red[tid] += red[tid + off];
             __syncthreads();
         }
-        if (tid == 0) out[o] = red[0];
+        if (tid == 0) res[P.job[o].out] = red[0];
         __syncthreads();
+    }
+    __syncthreads();
+    // results -> device scalar block (every slot this launch produced) and -> host
+    if (tid < 16) {
+        bool mine = false;
+        for (int o = 0; o < P.njobs; ++o) mine = mine || (P.job[o].out == tid);
+        if (tid >= P.ints_out && tid < P.ints_out + P.nints) mine = true;
+        if (mine) P.out[tid] = res[tid];
+        if (P.host && tid >= P.host_lo && tid < P.host_lo + P.host_n) P.host[tid] = mine ? res[tid] : P.out[tid];
     }
 }
 
@@ -957,7 +985,7 @@ __global__ __launch_bounds__(256) void prolong_kernel(int64_t rows, const int32_
 
 __global__ __launch_bounds__(256) void step_kernel(const double* __restrict__ x, const double* __restrict__ nn,
                                                    double s, double* __restrict__ xn, int64_t len,
-                                                   int32_t* __restrict__ moved) {
+                                                   int32_t* __restrict__ moved, int32_t stamp) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool m = false;
     if (i < len) {
@@ -973,7 +1001,8 @@ __global__ __launch_bounds__(256) void step_kernel(const double* __restrict__ x,
     __syncthreads();
     if (m) any_moved = 1;
     __syncthreads();
-    if (threadIdx.x == 0 && any_moved) *moved = 1;
+    // the flag carries the caller's stamp of THIS step (a fresh value per launch): nobody has to clear it beforehand
+    if (threadIdx.x == 0 && any_moved) *moved = stamp;
 }
 
 __global__ __launch_bounds__(256) void scale_copy_kernel(const double* __restrict__ src, double alpha,
@@ -1556,6 +1585,7 @@ void launch_reduce_partials(const double* partials, int64_t count, double* out, 
     MGB_HIP_CHECK(hipGetLastError());
 }
 
+
 static int reduce_blocks(int64_t n) {
     int64_t b = (n + 255) / 256;
     if (b > 1024) b = 1024;
@@ -1586,27 +1616,82 @@ void launch_index_scatter(const double* in, const int32_t* idx, int64_t cnt, dou
     MGB_HIP_CHECK(hipGetLastError());
 }
 
+static void launch_finish(const FinishParams& F, hipStream_t st) {
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, F);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
 void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats, hipStream_t st, const double* mask,
                       const int32_t* ints, int nints) {
     const int nb = reduce_blocks(n);
     hipLaunchKernelGGL(block_reduce_kernel<1>, dim3(nb), dim3(256), 0, st, v, (const double*)nullptr, n, scratch, mask);
-    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats, 2, ints, nints);
-    MGB_HIP_CHECK(hipGetLastError());
+    FinishParams F{};
+    F.job[0] = FinishJob{scratch, nb, 0};
+    F.job[1] = FinishJob{scratch + nb, nb, 1};
+    F.njobs = 2;
+    F.out = stats;
+    F.ints = const_cast<int32_t*>(ints); F.nints = nints; F.ints_out = 2; F.reset = 0;
+    launch_finish(F, st);
 }
 
 void launch_dir_stats(const double* v, const double* g, int64_t n, double* scratch, double* stats3, hipStream_t st,
                       const double* mask, const int32_t* ints, int nints) {
     const int nb = reduce_blocks(n);
     hipLaunchKernelGGL(dir_stats_kernel, dim3(nb), dim3(256), 0, st, v, g, n, scratch, mask);
-    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, stats3, 3, ints, nints);
-    MGB_HIP_CHECK(hipGetLastError());
+    FinishParams F{};
+    F.job[0] = FinishJob{scratch, nb, 0};
+    F.job[1] = FinishJob{scratch + nb, nb, 1};
+    F.job[2] = FinishJob{scratch + 2 * nb, nb, 2};
+    F.njobs = 3;
+    F.out = stats3;
+    F.ints = const_cast<int32_t*>(ints); F.nints = nints; F.ints_out = 3; F.reset = 0;
+    launch_finish(F, st);
+}
+
+// The Newton direction's read-back in one finishing launch: scal[2] = sum v^2, scal[3] = non-finite count, scal[4] = g.v,
+// scal[5], scal[6] = the solver's status flags (read AND cleared: the next factorization / condensing f2 finds them zero
+// without a memset launch); scal[2..7) also lands in the pinned host block `host` (same indices).
+void launch_dir_finish(const double* v, const double* g, int64_t n, double* scratch, double* scal, int32_t* status2, double* host,
+                       hipStream_t st, const double* mask) {
+    const int nb = reduce_blocks(n);
+    hipLaunchKernelGGL(dir_stats_kernel, dim3(nb), dim3(256), 0, st, v, g, n, scratch, mask);
+    FinishParams F{};
+    F.job[0] = FinishJob{scratch, nb, 2};
+    F.job[1] = FinishJob{scratch + nb, nb, 3};
+    F.job[2] = FinishJob{scratch + 2 * nb, nb, 4};
+    F.njobs = 3;
+    F.out = scal;
+    F.ints = status2; F.nints = 2; F.ints_out = 5; F.reset = 1;
+    F.host = host; F.host_lo = 2; F.host_n = 5;
+    launch_finish(F, st);
+}
+
+// One line-search trial's read-back: scal[0] = f0 (sum of the element kernel's workgroup partials), scal[2] = |g|^2,
+// scal[3] = non-finite count of g, scal[4] = the step kernel's "moved" stamp; scal[0..5) -> host.
+void launch_trial_finish(const double* g, int64_t n, double* scratch, const double* f0_partials, int64_t f0_count, double* scal,
+                         int32_t* moved, double* host, hipStream_t st, const double* mask) {
+    const int nb = reduce_blocks(n);
+    hipLaunchKernelGGL(block_reduce_kernel<1>, dim3(nb), dim3(256), 0, st, g, (const double*)nullptr, n, scratch, mask);
+    FinishParams F{};
+    int nj = 0;
+    if (f0_partials) F.job[nj++] = FinishJob{f0_partials, f0_count, 0};
+    F.job[nj++] = FinishJob{scratch, nb, 2};
+    F.job[nj++] = FinishJob{scratch + nb, nb, 3};
+    F.njobs = nj;
+    F.out = scal;
+    F.ints = moved; F.nints = 1; F.ints_out = 4; F.reset = 0;
+    F.host = host; F.host_lo = 0; F.host_n = 5;
+    launch_finish(F, st);
 }
 
 void launch_dot(const double* a, const double* b, int64_t n, double* scratch, double* out, hipStream_t st, const double* mask) {
     const int nb = reduce_blocks(n);
     hipLaunchKernelGGL(block_reduce_kernel<0>, dim3(nb), dim3(256), 0, st, a, b, n, scratch, mask);
-    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, st, scratch, nb, out, 1, (const int32_t*)nullptr, 0);
-    MGB_HIP_CHECK(hipGetLastError());
+    FinishParams F{};
+    F.job[0] = FinishJob{scratch, nb, 0};
+    F.njobs = 1;
+    F.out = out;
+    launch_finish(F, st);
 }
 
 void launch_csr_matvec(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val,
@@ -1644,10 +1729,10 @@ void launch_prolong(int64_t rows, const int32_t* ptr, const int32_t* col, const 
     MGB_HIP_CHECK(hipGetLastError());
 }
 
-void launch_step(const double* x, const double* n, double s, double* xn, int64_t len, int32_t* moved,
+void launch_step(const double* x, const double* n, double s, double* xn, int64_t len, int32_t* moved, int32_t stamp,
                  hipStream_t st) {
     if (len == 0) return;
-    hipLaunchKernelGGL(step_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, x, n, s, xn, len, moved);
+    hipLaunchKernelGGL(step_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, x, n, s, xn, len, moved, stamp);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

@@ -93,6 +93,14 @@ void launch_vec_stats(const double* v, int64_t n, double* scratch, double* stats
 void launch_dir_stats(const double* v, const double* g, int64_t n, double* scratch, double* stats3, hipStream_t st,
                       const double* mask = nullptr, const int32_t* ints = nullptr, int nints = 0);
 void launch_dot(const double* a, const double* b, int64_t n, double* scratch, double* out, hipStream_t st, const double* mask = nullptr);
+// The two read-backs of a Newton iteration, each ONE finishing launch that also writes the pinned host block `host`
+// (device-visible pointer of a hipHostMalloc block; same slot indices as `scal`) -- no copy launch, no memset launch:
+//   direction: scal[2] = sum v^2, [3] = non-finite count of v, [4] = g.v, [5], [6] = status2[0..1] (read, then cleared)
+//   trial:     scal[0] = sum of f0_partials (nullptr: scal[0] is already final), [2] = sum g^2, [3] = non-finite count, [4] = *moved
+void launch_dir_finish(const double* v, const double* g, int64_t n, double* scratch, double* scal, int32_t* status2, double* host,
+                       hipStream_t st, const double* mask = nullptr);
+void launch_trial_finish(const double* g, int64_t n, double* scratch, const double* f0_partials, int64_t f0_count, double* scal,
+                         int32_t* moved, double* host, hipStream_t st, const double* mask = nullptr);
 void launch_index_gather(const double* v, const int32_t* idx, int64_t cnt, double* out, hipStream_t st);     // out[i] = v[idx[i]]
 void launch_index_scatter(const double* in, const int32_t* idx, int64_t cnt, double* v, hipStream_t st);    // v[idx[i]] = in[i]
 int64_t reduce_scratch_doubles(int64_t n);
@@ -106,8 +114,8 @@ void launch_csr_matvec_chunked(int64_t rows, const int32_t* ptr, const int32_t* 
                                const double* x, double* y, double* scratch, int nchunk, hipStream_t st);
 void launch_prolong(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val, const double* s,
                     const double* z0, double* zfull, hipStream_t st);
-// xn = x - s*n ; flag[0] |= any(xn != x)
-void launch_step(const double* x, const double* n, double s, double* xn, int64_t len, int32_t* moved,
+// xn = x - s*n ; flag[0] = stamp if any(xn != x)  (a fresh stamp per launch: the flag never needs clearing)
+void launch_step(const double* x, const double* n, double s, double* xn, int64_t len, int32_t* moved, int32_t stamp,
                  hipStream_t st);
 void launch_scale_copy(const double* src, double alpha, double* dst, int64_t len, hipStream_t st);
 void launch_border_tail(const double* g, double* tail, int64_t m, hipStream_t st);   // tail = [-g; -1]

@@ -1862,6 +1862,19 @@ __global__ __launch_bounds__(256, 3) void mf_big_step(const FrontDev* __restrict
     PROBE(4);
 }
 
+// Interface front of a domain-decomposed system: only its lower triangle is meaningful, so only that crosses ranks --
+// packed column by column (column c at c*m - c(c-1)/2, rows c .. m-1), summed, unpacked in place.
+__global__ __launch_bounds__(256) void mf_tri_pack(int m, const double* __restrict__ F, double* __restrict__ packed, int unpack,
+                                                   double* __restrict__ Fout) {
+    const int c = blockIdx.x;
+    if (c >= m) return;
+    const int64_t base = (int64_t)c * m - ((int64_t)c * (c - 1)) / 2;
+    for (int r = c + threadIdx.x; r < m; r += 256) {
+        if (unpack) Fout[r + (int64_t)c * m] = packed[base + (r - c)];
+        else packed[base + (r - c)] = F[r + (int64_t)c * m];
+    }
+}
+
 // First diagonal block of every front of a batch, factored and inverted once (one workgroup per front)
 // into slot 0.  Used for batches of many fronts, where the redundant factorization inside every trailing
 // tile of step 0 (do_diag) would occupy all compute units with copies of the same 32 x 32 problem.
@@ -1903,7 +1916,8 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
                                                      const int32_t* __restrict__ a_dst,
                                                      const int32_t* __restrict__ a_colptr,
                                                      const double* __restrict__ Hval, double* __restrict__ arena, int mstride,
-                                                     double* __restrict__ dscr, int32_t* __restrict__ status, int with_diag) {
+                                                     double* __restrict__ dscr, int32_t* __restrict__ status, int with_diag,
+                                                     int ct /* destination columns per workgroup */) {
     extern __shared__ int32_t inv[];               // [nchild][mstride]: position in the child's update block or -1
     __shared__ int64_t cU[GATHER_MAX_CHILD];
     __shared__ int64_t cR[GATHER_MAX_CHILD];
@@ -1983,9 +1997,9 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
         }
         return;
     }
-    const int c0 = blockIdx.x * CT;
+    const int c0 = blockIdx.x * ct;
     if (c0 >= m) return;
-    const int c1 = min(c0 + CT, m);
+    const int c1 = min(c0 + ct, m);
     double* W = arena + F.F_off;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;     // one wave per destination column, lanes on the rows
@@ -2387,6 +2401,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     d_arena.alloc((size_t)std::max<int64_t>(plan.arena_doubles, 1));
     d_uvec.alloc((size_t)std::max<int64_t>(plan.uvec_doubles, 1));
     d_y.alloc((size_t)plan.n + 1);            // + the border unknown
+    y_zero = y_border_one = status_zero = leaf_zero = false;
     y_border_one = false;
     d_bx.alloc((size_t)plan.n + 1);
     d_xx.alloc((size_t)plan.n + 1);
@@ -2675,9 +2690,14 @@ bool MfSolver::launch_big_assemble(const MfLaunch& L, dim3 ga, const double* d_v
                                    bool with_diag) {
     const size_t lds = (size_t)L.max_child * (size_t)L.max_m * sizeof(int32_t);
     if (L.max_child >= 1 && L.max_child <= GATHER_MAX_CHILD && lds <= 40 * 1024) {
+        // few fronts: one destination column per wave (a level with one to eight fronts is a latency chain: twice the
+        // workgroups halve the columns each wave walks through); many fronts: two per wave, half the per-workgroup set-up
+        static const int ct_few = [] { const char* e = getenv("MGBHIP_GATHER_CT"); return e ? atoi(e) : 4; }();
+        const int ct = (L.count <= 8 && ct_few >= 4 && ct_few <= CT) ? ct_few : CT;
+        ga.x = (unsigned)((L.max_m + ct - 1) / ct);
         if (with_diag) ga.x += 1;          // the diagonal-block workgroup
         hipLaunchKernelGGL(mf_big_gather, ga, dim3(256), lds, st, cur_fr, L.first, d_children.p, d_rel.p, a_src_p,
-                           cur_adst, cur_acol, d_values, d_arena.p, L.max_m, d_dscr.p, d_status.p, with_diag ? 1 : 0);
+                           cur_adst, cur_acol, d_values, d_arena.p, L.max_m, d_dscr.p, d_status.p, with_diag ? 1 : 0, ct);
         return with_diag;
     } else
         hipLaunchKernelGGL(mf_big_assemble, ga, dim3(256), 0, st, cur_fr, L.first, d_children.p, d_rel.p, a_src_p,
@@ -2710,7 +2730,8 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
     MGB_REQUIRE(analyzed, "MfSolver::factor before analyze");
     if (timers) timers->begin("factor");
     factored_inv = !robust;
-    MGB_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));      // [1], the leaf flag of a condensing f2, stays
+    if (!status_zero) MGB_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));      // [1], the leaf flag of a condensing f2, stays
+    status_zero = false;
     factored_condensed = condensed;
     static const bool lvl_timing = [] { const char* e = getenv("MGBHIP_LEVEL_TIMING"); return e && e[0] == '1'; }();
     int lvno = -1;
@@ -2757,7 +2778,13 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                 const Front& fi = plan.fronts[L.first];
                 const dim3 ga((L.max_m + CT - 1) / CT, 1);
                 launch_big_assemble(L, ga, d_values, a_src_p, st, false);
-                iface_reduce(d_arena.p + fi.F_off, (int64_t)fi.m * fi.m);
+                {   // sum the lower triangle over ranks: (m + 1) m / 2 doubles instead of m^2
+                    const int64_t tri = (int64_t)fi.m * (fi.m + 1) / 2;
+                    d_ifpack.ensure((size_t)tri);
+                    hipLaunchKernelGGL(mf_tri_pack, dim3(fi.m), dim3(256), 0, st, fi.m, d_arena.p + fi.F_off, d_ifpack.p, 0, (double*)nullptr);
+                    iface_reduce(d_ifpack.p, tri);
+                    hipLaunchKernelGGL(mf_tri_pack, dim3(fi.m), dim3(256), 0, st, fi.m, (const double*)nullptr, d_ifpack.p, 1, d_arena.p + fi.F_off);
+                }
                 if (L.inv && !robust) {
                     hipLaunchKernelGGL(mf_big_diag0, dim3(1), dim3(256), 0, st, cur_fr, L.first, d_arena.p, d_dscr.p, d_status.p);
                     for (int j0 = 0; j0 < L.max_k; j0 += NB) {
@@ -2835,7 +2862,10 @@ void MfSolver::solve_border(double* d_x_np1, hipStream_t st, StageTimers* timers
     // factors of [H -g; -g' -1]: the forward substitution of H x = g already ran as the border row of every
     // front.  L' x = e_n backwards from x_n = 1 gives x[0:n] = H^{-1} g.
     const size_t n = (size_t)plan.n;
-    MGB_HIP_CHECK(hipMemsetAsync(d_y.p, 0, n * sizeof(double), st));
+    if (!y_zero) {                   // the backward sweeps only read y: it stays zero from one Newton iteration to the next
+        MGB_HIP_CHECK(hipMemsetAsync(d_y.p, 0, n * sizeof(double), st));
+        y_zero = true;
+    }
     if (!y_border_one) {             // y[n] = 1 survives the backward sweeps: set once (a generic forward sweep overwrites it)
         MGB_HIP_CHECK(hipMemcpyAsync(d_y.p + n, d_one.p, sizeof(double), hipMemcpyDeviceToDevice, st));
         y_border_one = true;
@@ -2847,6 +2877,7 @@ void MfSolver::solve_border(double* d_x_np1, hipStream_t st, StageTimers* timers
 
 void MfSolver::forward_pass(const double* d_b, hipStream_t st, StageTimers* timers) {
     y_border_one = false;
+    y_zero = false;
     static const bool lvl_timing = [] { const char* e = getenv("MGBHIP_LEVEL_TIMING"); return e && e[0] == '1'; }();
     int lvno = -1;
     for (auto& lev : level_solves) {
@@ -2942,6 +2973,32 @@ void mf_debug_probe(long long* out64) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe), init, sizeof(init));
 }
 #endif
+
+void MfSolver::chain_stats(double* out) const {
+    double blocks = 0, big_levels = 0, fac = 0, bwd = 0, extra = 0;
+    for (auto& lev : level_launches) {
+        int lev_blocks = 0;
+        for (auto& L : lev) {
+            if (L.count == 0) continue;
+            if (L.tiny || L.wave || L.cls) { fac += 1; continue; }
+            const int nb = (L.max_k + NB - 1) / NB;
+            lev_blocks = std::max(lev_blocks, nb);
+            fac += 1 + nb + (L.iface ? 3 : 0);
+            for (int32_t q = L.first; q < L.first + L.count; ++q) {
+                const Front& f = plan.fronts[q];
+                const double mk = (double)(f.m - f.k), steps = (double)((f.k + NB - 1) / NB);
+                // every 32-column step reads and writes the trailing lower triangle it updates; one pass is the floor
+                extra += 2.0 * 0.5 * (mk * mk + mk * f.k) * std::max(0.0, steps - 1.0);
+            }
+        }
+        if (lev_blocks) { big_levels += 1; blocks += lev_blocks; }
+    }
+    for (auto& lev : level_solves)
+        for (auto& L : lev)
+            if (L.count) bwd += 1;
+    out[0] = blocks; out[1] = big_levels; out[2] = fac; out[3] = bwd;
+    out[4] = (double)plan.arena_doubles; out[5] = (double)plan.factor_flops; out[6] = extra; out[7] = 0.0;
+}
 
 void MfSolver::status_async(int32_t* h_dst2, hipStream_t st) const {
     MGB_HIP_CHECK(hipMemcpyAsync(h_dst2, d_status.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));

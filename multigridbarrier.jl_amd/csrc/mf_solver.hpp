@@ -61,6 +61,12 @@ class MfSolver {
     double* arena() { return d_arena.p; }
     int32_t* leaf_status() { return d_status.p + 1; }
     const int32_t* status_flags() const { return d_status.p; }      // [0] factorization, [1] leaf pivots (device)
+    // The Newton loop reads both flags through a finishing kernel that also clears them (kernels.hpp, launch_dir_finish)
+    // and tells the solver so: factor() / the condensing f2 then skip their hipMemsetAsync.
+    int32_t* status_flags_rw() { return d_status.p; }
+    void flags_cleared() { status_zero = true; leaf_zero = true; }
+    bool leaf_flag_zero() const { return leaf_zero; }
+    void leaf_flag_used() { leaf_zero = false; }
     // Second scatter list for the same plan: CSR position q -> value_map[q], border entry v -> tail_base + v.
     void set_direct_map(const int32_t* value_map, int64_t nnz, int64_t tail_base, hipStream_t st);
     bool has_direct_map() const { return d_a_src_direct.n > 0; }
@@ -73,6 +79,12 @@ class MfSolver {
     void solve(const double* d_b, double* d_x, hipStream_t st, StageTimers* timers);
     // x[0:n] = H^{-1} g for factors of the c = -g border; d_x_np1 has room for n + 1 doubles (x[n] = 1 on return)
     void solve_border(double* d_x_np1, hipStream_t st, StageTimers* timers);
+    // Shape of one factorization + backward sweep as the device runs it (mgbhip_solver_chain): out[0] sequential
+    // 32-column pivot blocks on the critical path of the large fronts (sum over their tree levels of ceil(max_k / 32)),
+    // [1] tree levels on the large-front path, [2] kernel launches per factorization, [3] per backward sweep,
+    // [4] doubles of the frontal arena, [5] factorization flops, [6] doubles the large fronts' trailing updates read + write
+    // beyond one pass over the arena (the re-reads a tile-resident factorization would not make), [7] reserved
+    void chain_stats(double* out8) const;
     int status(hipStream_t st);     // synchronises; MGBHIP_OK or MGBHIP_ERR_NOT_SPD
     // enqueue the copy of the flag only (pinned destination); interpret it after the caller's sync
     void status_async(int32_t* h_dst, hipStream_t st) const;
@@ -99,6 +111,7 @@ class MfSolver {
     DevBuf<int32_t> d_front_idx, d_children, d_rel, d_a_src, d_a_src_direct, d_a_dst, d_a_colptr;
     DevBuf<int64_t> d_ug_ptr, d_ug_src;   // per large front: for every local index the children's update-vector entries, in child order
     DevBuf<double> d_arena, d_uvec, d_y, d_tbig, d_tsol, d_dscr, d_dvec;
+    DevBuf<double> d_ifpack;              // packed lower triangle of the interface front (domain decomposition)
     DevBuf<int32_t> d_status;
     // condensed leaves
     bool condensed_ok = false;
@@ -116,6 +129,8 @@ class MfSolver {
     int32_t lds_cap = 88;           // largest m factored out of LDS
     bool uses_inv = false;
     bool y_border_one = false;      // d_y[n] holds the 1 the border sweep starts from
+    bool y_zero = false;            // d_y[0:n) is zero (the backward sweeps only read it; a generic forward sweep overwrites it)
+    bool status_zero = false, leaf_zero = false;    // d_status[0] / [1] are known to be zero on the stream
 };
 
 }  // namespace mgbhip

@@ -673,7 +673,8 @@ ElemParams mgbhip_problem::base_params(int level, const double* d_s, const doubl
         const Level& L = levels[level];
         if (zf_stamp == zstamp && zf_level == level && zf_s == d_s && zf_z == d_zz) {
             // same evaluation point as the previous call: d_zfull is still valid
-        } else if (L.R_unit) {
+        } else if (L.R_unit && !dense) {
+            // (the dense spectral path, launch_dense_eval, reads E.z0 only: it never takes this branch)
             // selection level: the element kernel gathers s itself and leaves z0 + R s in d_zfull for the next evaluation
             // at this point (the Hessian at an accepted line-search trial reads it back instead of chaining two gathers)
             E.zsel = L.Rsel.p;
@@ -776,7 +777,7 @@ void mgbhip_problem::eval_f1(int level, const double* d_s, const double* d_zz, c
 }
 
 void mgbhip_problem::eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout,
-                                     double* d_part) {
+                                     double* d_part, bool defer_f0_sum) {
     if (dense) {                    // the dense (spectral) path keeps its separate GEMV pipelines
         eval_f0_launch(level, d_s, d_zz, d_cc);
         eval_f1(level, d_s, d_zz, d_cc, d_gout, d_part);
@@ -788,7 +789,7 @@ void mgbhip_problem::eval_f01_launch(int level, const double* d_s, const double*
         StageScope sc(ctx->timers, level + 1 == (int)levels.size() ? "f01" : "f01_coarse");
         ElemParams E = base_params(level, d_s, d_zz, d_cc);
         launch_elem(E, MODE_F01, st);
-        launch_reduce_partials(d_partials.p, elem_grid(p, N), d_scal.p, st);
+        if (!defer_f0_sum) launch_reduce_partials(d_partials.p, elem_grid(p, N), d_scal.p, st);
     }
     {
         StageScope sc(ctx->timers, "restrict");
@@ -843,7 +844,8 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
         E.leaf_slack0 = L.m - n;
         E.leaf_status = L.solver.leaf_status();
         E.leaf_packed = L.solver.leaves_packed() ? 1 : 0;
-        MGB_HIP_CHECK(hipMemsetAsync(E.leaf_status, 0, sizeof(int32_t), st));
+        if (!L.solver.leaf_flag_zero()) MGB_HIP_CHECK(hipMemsetAsync(E.leaf_status, 0, sizeof(int32_t), st));
+        L.solver.leaf_flag_used();
         if (launch_elem_f2_condense(E, st)) {
             L.have_H = true;
             L.H_in_slab = true;
@@ -977,6 +979,23 @@ void mgbhip_problem::factor(int level, const double* rhs) {
     L.solver.factor(L.Hval.p, st, &ctx->timers);
     L.factored = true;
     cnt.factor++;
+}
+
+bool mgbhip_problem::lu_fallback(int level, const double* d_g, double* d_xout) {
+    Level& L = levels[level];
+    static const bool off = [] { const char* e = getenv("MGBHIP_NO_LU_FALLBACK"); return e && e[0] == '1'; }();
+    if (off || sharded() || !L.have_H || L.H_in_slab || L.m < 1 || L.m > DENSE_LU_MAX_M || L.Hval.n < (size_t)L.nnz || !L.Hptr.p || !L.Hcol.p)
+        return false;
+    hipStream_t st = stream();
+    d_lu.ensure((size_t)L.m * (size_t)L.m);
+    d_lustat.ensure(1);
+    d_lustat.zero(st, 1);
+    launch_dense_lu_solve((int)L.m, L.Hptr.p, L.Hcol.p, L.Hval.p, d_lu.p, d_g, d_xout, d_lustat.p, st);
+    int32_t bad = 1;
+    d_lustat.download(&bad, 1, st);
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (bad == 0) ++lu_fallbacks;
+    return bad == 0;
 }
 
 void mgbhip_problem::trisolve(int level, const double* d_g, double* d_xout) {

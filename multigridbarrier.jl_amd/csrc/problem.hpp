@@ -110,6 +110,7 @@ struct mgbhip_problem {
     mgbhip::DevBuf<double> d_z, d_z0, d_zfull, d_c, d_ret, d_hel, d_partials, d_scal, d_scratch, d_nodeF, d_nodeDz, d_dnDz, d_dnY, d_tchunk;
     mgbhip::DevBuf<double> d_x, d_g, d_nv, d_xn, d_gn, d_tmp, d_c0;
     mgbhip::DevBuf<int32_t> d_flag;
+    int32_t step_stamp = 0;                // launch_step writes ++step_stamp into d_flag[0] when the step moved the iterate
     mgbhip::PinnedBuf pin;                 // scalar read-backs of the Newton loop
     mgbhip::Counters cnt;
     // z0 + R*s is cached in d_zfull across the f0/f1/f2 calls at one point: the key is the
@@ -143,7 +144,9 @@ struct mgbhip_problem {
     // d_part (sharded problems): receives this rank's partial gradient before the interface entries are summed
     void eval_f1(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout, double* d_part = nullptr);
     // one line-search trial: f0 (value in d_scal[0]) and f1 (gradient in d_gout) from one sweep over the elements
-    void eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout, double* d_part = nullptr);
+    // defer_f0_sum: leave the workgroup partials of f0 in d_partials for the caller's finishing launch (launch_trial_finish)
+    void eval_f01_launch(int level, const double* d_s, const double* d_zz, const double* d_cc, double* d_gout, double* d_part = nullptr,
+                         bool defer_f0_sum = false);
     // materialize = false (Newton loop): on direct levels only the shared entries are summed, H is not formed as a CSR
     // value array and the next factor(level, rhs) reads the slab (valid until the next eval_f2 of any level)
     // rhs (with materialize = false): the gradient the following factor(level, rhs) will carry; on levels with
@@ -160,4 +163,12 @@ struct mgbhip_problem {
     void factor(int level, const double* rhs = nullptr);
     void trisolve(int level, const double* d_g, double* d_xout);
     void trisolve_carried(int level, double* d_xout_np1);      // output has room for m + 1 doubles
+    // The reference's last resort when the symmetric factorizations fail (Julia's `Symmetric(H) \ g`: Cholesky -> LDL' -> LU,
+    // src/utils.jl:142-145): dense LU with partial pivoting ON THE DEVICE (dense.hpp) for systems of at most DENSE_LU_MAX_M
+    // unknowns whose H exists as a CSR value array.  d_xout = H^{-1} d_g.  Returns false when it does not apply (large or
+    // slab-resident H, domain-decomposed problem) or the matrix is singular to working precision.
+    bool lu_fallback(int level, const double* d_g, double* d_xout);
+    mgbhip::DevBuf<double> d_lu;
+    mgbhip::DevBuf<int32_t> d_lustat;
+    int64_t lu_fallbacks = 0;              // how often the fallback produced the direction (diagnostics)
 };

@@ -110,7 +110,7 @@ EXPORTS = [
     "mgbhip_set_hessian", "mgbhip_solve_newton", "mgbhip_newton_direction", "mgbhip_problem_set_sharding",
     "mgbhip_problem_set_collective",
     "mgbhip_node_barrier", "mgbhip_node_slack", "mgbhip_mgb_core", "mgbhip_matched_t",
-    "mgbhip_default_options", "mgbhip_stage_ms", "mgbhip_reset_stage_timers", "mgbhip_solver_stats",
+    "mgbhip_default_options", "mgbhip_stage_ms", "mgbhip_reset_stage_timers", "mgbhip_solver_stats", "mgbhip_solver_chain",
     "mgbhip_vec_alloc", "mgbhip_vec_free", "mgbhip_vec_len", "mgbhip_vec_upload", "mgbhip_vec_download",
     "mgbhip_vec_fill", "mgbhip_vec_copy", "mgbhip_vec_axpy", "mgbhip_vec_scale", "mgbhip_vec_dot",
     "mgbhip_vec_norm", "mgbhip_vec_isfinite", "mgbhip_f0_d", "mgbhip_f1_d", "mgbhip_f2_d", "mgbhip_solve_d",
@@ -165,6 +165,7 @@ def load_library():
     lib.mgbhip_stage_ms.argtypes = [C.c_void_p, C.c_char_p, _dp, C.POINTER(C.c_int64)]
     lib.mgbhip_reset_stage_timers.argtypes = [C.c_void_p, C.c_int]
     lib.mgbhip_solver_stats.argtypes = [C.c_void_p, C.c_int32, _dp]
+    lib.mgbhip_solver_chain.argtypes = [C.c_void_p, C.c_int32, _dp]
     vp = C.c_void_p
     lib.mgbhip_vec_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
     lib.mgbhip_vec_free.argtypes = [vp]
@@ -542,9 +543,11 @@ class DeviceProblem:
         a = None if bw is None else _f64(bw)
         _check(self.lib, self.lib.mgbhip_problem_set_barrier_weights(self.handle, _ptr(a)))
 
-    def default_options(self) -> Options:
+    def default_options(self, n_nodes: Optional[int] = None) -> Options:
+        """Reference defaults (src/mgb.jl:95-101, :360); the stopping tolerance 0.25 / sqrt(n) uses the node count of
+        the WHOLE mesh (`n_nodes`: a domain-decomposed problem passes the global count, this image holds a slice)."""
         o = Options()
-        self.lib.mgbhip_default_options(C.byref(o), self.n)
+        self.lib.mgbhip_default_options(C.byref(o), int(self.n if n_nodes is None else n_nodes))
         return o
 
     def mgb_core(self, z, c, opt: Options, cap_steps: int = 256):
@@ -588,6 +591,13 @@ class DeviceProblem:
         out = np.zeros(8)
         _check(self.lib, self.lib.mgbhip_solver_stats(self.handle, level, _ptr(out)))
         keys = ("fronts", "max_front", "arena_doubles", "factor_flops", "peeled", "tree_levels", "nnz", "unknowns")
+        return dict(zip(keys, out.tolist()))
+
+    def solver_chain(self, level: int) -> dict:
+        out = np.zeros(8)
+        _check(self.lib, self.lib.mgbhip_solver_chain(self.handle, level, _ptr(out)))
+        keys = ("pivot_blocks_on_critical_path", "large_front_tree_levels", "launches_per_factorization",
+                "launches_per_backward_sweep", "arena_doubles", "factor_flops", "extra_trailing_doubles", "reserved")
         return dict(zip(keys, out.tolist()))
 
     def close(self):

@@ -70,7 +70,7 @@ def _barrier_weights(w: np.ndarray, barrier_nodes):
 
 
 def _options(P, tol, t, kappa, maxit, max_newton, line_search, stopping_criterion, finalize, early_stop,
-             early_stop_fn=None, keep=None):
+             early_stop_fn=None, keep=None, n_nodes=None):
     """Reference keyword arguments -> `mgbhip_options`.  `stopping_criterion` is either a tagged tuple
     selecting a built-in rule or any callable with the reference's signature
     `stop(ymin, ynext, gmin, gnext, n, ndecmin, ndec) -> bool` (src/newton.jl:187,222-225): `gnext` arrives
@@ -78,7 +78,7 @@ def _options(P, tol, t, kappa, maxit, max_newton, line_search, stopping_criterio
     stay on the device; `early_stop_fn` any callable
     `z -> bool` or `(z, t) -> bool` on the stacked iterate (src/mgb.jl:85-89).  Callables cross the C
     ABI as function pointers; `keep` collects the ctypes thunks so they outlive the call."""
-    o = P.default_options()
+    o = P.default_options(n_nodes)       # n_nodes: node count of the whole mesh when P holds one rank's slice (sharded.py)
     if tol is not None:
         o.tol = float(tol)
     o.t = float(t)
@@ -327,7 +327,7 @@ def mgb_driver(D: DeviceMGBProblem, t: float = 0.1, t_feasibility: Optional[floa
     ncomp = z0.shape[1]
     z2 = np.ascontiguousarray(z0.T).reshape(-1).copy()
     common = dict(tol=tol, kappa=kappa, maxit=maxit, max_newton=max_newton, line_search=line_search,
-                  stopping_criterion=stopping_criterion, finalize=finalize)
+                  stopping_criterion=stopping_criterion, finalize=finalize, n_nodes=_shard["n_global"] if _shard else None)
     SOL_feasibility = None
     F, w_Dz = main.node_barrier(z2, want_Dz=True)
     if not rall(bool(np.all(np.isfinite(F)))):

@@ -11,6 +11,8 @@ import numpy as np
 import mgb_amd as m
 from oracle import mgb_oracle as O
 
+if os.environ.get("ORACLE_SOLVER") == "mf":      # host multifrontal Cholesky instead of SuperLU (3-D meshes: SuperLU's fill is prohibitive)
+    O.set_solver("mf")
 fam, L, p = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
 kw = {}
 if len(sys.argv) > 4:

@@ -102,3 +102,81 @@ def test_one_wave_mfma_ldlt32_matches_host_ldlt_and_flags_zero_pivots():
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [l for l in out.stdout.splitlines() if l.startswith("nb=") or l.startswith("zero pivot")]
     assert len(lines) == 7 and all(l.rstrip().endswith("ok") for l in lines), out.stdout
+
+
+def test_zero_pivot_falls_back_to_the_pivoted_lu_like_the_reference():
+    """`solve(symmetric(H), g)` is Julia's `Symmetric(H) \\ g`: Cholesky, then LDL', then LU when the symmetric
+    factorizations meet a zero pivot (src/utils.jl:142-145).  The device LDL' is un-pivoted; an exactly zero pivot used to
+    end the Newton attempt as "not converged" (missing #1).  Now systems small enough to be held densely take
+    the reference's last resort on the device: dense LU with partial pivoting (csrc/dense.hip).  Indefinite-but-regular
+    matrices on the levels' own patterns, each with a ZERO leading entry so that the un-pivoted factorization must fail:
+    both solve paths return H^{-1} g to 1e-9; a singular matrix still reports MGBHIP_ERR_NOT_SPD; and with
+    MGBHIP_NO_LU_FALLBACK=1 (worker process) the zero pivot is an error as before."""
+    import mgb_amd as m
+    import scipy.sparse as sp
+    from mgb_amd import device as dev
+    from mgb_amd.device import DeviceMGBProblem
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 4)), p=1.5)
+    D = DeviceMGBProblem(prob)
+    rng = np.random.default_rng(3)
+    try:
+        P = D.main
+        tried = 0
+        for lev, msz in enumerate(P.level_sizes):
+            if msz > 2048:
+                continue
+            indptr, indices = P.hessian_pattern(lev)
+            v = rng.standard_normal(indices.size)
+            A = sp.csr_matrix((v, indices, indptr), shape=(msz, msz))
+            A = sp.csr_matrix((A + A.T) * 0.5 + sp.diags(rng.choice([-3.0, 3.0], msz)))      # symmetric, indefinite
+            A = sp.lil_matrix(A)
+            A[0, 0] = 0.0                                                                      # the first pivot of the LDL' is exactly zero
+            A = sp.csr_matrix(A)
+            A.sort_indices()
+            if msz > 1:
+                assert abs(A[0, 1:]).sum() > 0                                                 # ... but the matrix is regular
+            Ad = np.asarray(A.todense())
+            if msz == 1 or abs(np.linalg.det(Ad / np.abs(Ad).max())) < 1e-12:
+                continue
+            vals = np.zeros(indices.size)
+            vals[:] = np.asarray(A[np.repeat(np.arange(msz), np.diff(indptr)), indices]).ravel()      # explicit zeros keep their slot
+            g = rng.standard_normal(msz)
+            x_ref = np.linalg.solve(np.triu(Ad) + np.triu(Ad, 1).T, g)
+            P.set_hessian(lev, vals)
+            x = P.solve(lev, g)
+            assert np.linalg.norm(x - x_ref) <= 1e-9 * np.linalg.norm(x_ref), lev
+            P.set_hessian(lev, vals)
+            xn, lam, status = P.solve_newton(lev, g)
+            assert status == dev.OK and np.linalg.norm(xn - x_ref) <= 1e-9 * np.linalg.norm(x_ref), lev
+            assert abs(lam - g @ x_ref) <= 1e-9 * max(abs(g @ x_ref), np.linalg.norm(g) * np.linalg.norm(x_ref) * 1e-3)
+            tried += 1
+        assert tried >= 3
+        # a singular matrix stays an error: first row and column zero
+        lev = 1
+        msz = P.level_sizes[lev]
+        indptr, indices = P.hessian_pattern(lev)
+        rows = np.repeat(np.arange(msz), np.diff(indptr))
+        vals = np.where(rows == indices, 2.0, 0.0)
+        vals[(rows == 0) | (indices == 0)] = 0.0
+        P.set_hessian(lev, vals)
+        with pytest.raises(dev.MGBHipError) as ei:
+            P.solve(lev, np.ones(msz))
+        assert ei.value.status == dev.ERR_NOT_SPD
+    finally:
+        D.close()
+    # the switch restores round 3's behaviour: the zero pivot is reported
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, mgb_amd as m\n"
+            "from mgb_amd import device as dev\n"
+            "from mgb_amd.device import DeviceMGBProblem\n"
+            "D = DeviceMGBProblem(m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 2)), p=1.5)); P = D.main\n"
+            "ip, ix = P.hessian_pattern(0); n = P.level_sizes[0]\n"
+            "rows = np.repeat(np.arange(n), np.diff(ip)); v = np.where(rows == ix, 0.0, 1.0)\n"
+            "P.set_hessian(0, v)\n"
+            "try:\n    P.solve(0, np.ones(n)); print('SOLVED')\n"
+            "except dev.MGBHipError as e:\n    print('STATUS', e.status)\n") % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, MGBHIP_NO_LU_FALLBACK="1"))
+    assert "STATUS 3" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ))
+    assert "SOLVED" in out.stdout, out.stdout + out.stderr

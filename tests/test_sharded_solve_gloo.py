@@ -30,6 +30,10 @@ def _problem(kind):
         return m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 3)), p=1.5)
     if kind == "fem2d_P2_L5":
         return m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 5)), p=1.0)
+    if kind == "fem2d_P2_L7":
+        return m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 7)), p=1.0)
+    if kind == "fem3d_L6_config4":
+        return m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 6), prolongator=m.amg_ruge_stuben(max_coarse=500)), p=4.0)
     if kind == "fem3d_L3":
         return m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 3)), p=1.5)
     if kind == "phase1":                      # infeasible start: phase I, box, _matched_t hand-off across ranks
@@ -186,3 +190,119 @@ def test_sharded_mgb_solve_matches_single_rank_world2(kind):
         assert np.allclose(r["t"], ref.SOL_main["ts"])
         assert (r["feas"] is None) == (ref.SOL_feasibility is None)
     assert np.array_equal(res[0]["z"], res[1]["z"])                         # every rank returns the same solution
+
+
+@pytest.mark.gpu
+def test_sharded_mgb_solve_L7_same_z_and_iteration_counts_as_single_rank():
+    """BASELINE configs[1]'s mesh (fem2d_P2 L = 7, 57 344 nodes), p = 1.0, two ranks sharing the device: the sharded solve
+    must follow the single-rank trajectory -- same z (1e-8, the reference's cross-backend bar, test/test_cuda.jl:51) and
+    the same Newton iteration count in EVERY level solve of every t-step (+-1: sums run in another order).  Round 3's
+    rehearsal at L = 9 took 432 iterations where the single-rank solve takes 548: the default stopping rule
+    lambda < 0.25 / sqrt(n) (src/mgb.jl:360) was fed the slice's node count instead of the mesh's."""
+    import mgb_amd as m
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_gpu_worker, args=(world, _free_port(), "fem2d_P2_L7", out), nprocs=world, join=True)
+        res = dict(out)
+    ref = m.mgb_solve(_problem("fem2d_P2_L7"))
+    b = np.asarray(ref.SOL_main["its"])
+    for rank in range(world):
+        r = res[rank]
+        a = np.asarray(r["its"])
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1, (a.sum(axis=1), b.sum(axis=1))
+        assert abs(int(a.sum()) - int(b.sum())) <= 3
+        assert np.abs(r["z"] - ref.z).max() < 1e-8
+        assert np.allclose(r["t"], ref.SOL_main["ts"])
+    assert np.array_equal(res[0]["z"], res[1]["z"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU: host-side pieces of the sharded solve that need no GPU
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_sharded_default_stopping_rule_uses_the_global_node_count():
+    """src/mgb.jl:360: stopping_inexact(0.25 / sqrt(length(w)), 0.9) with w of the WHOLE mesh."""
+    import math
+    import sys
+    sys.path.insert(0, ROOT)
+    from mgb_amd import device as dev
+    from mgb_amd import solve
+
+    class SliceImage:                       # stands in for one rank's DeviceProblem (a slice of 1 000 nodes)
+        lib = dev.load_library()
+        n, nu = 1000, 2
+        default_options = dev.DeviceProblem.default_options
+    kw = dict(tol=None, t=0.1, kappa=None, maxit=None, max_newton=None, line_search=None, stopping_criterion=None,
+              finalize=None, early_stop=0)
+    assert solve._options(SliceImage(), **kw).stop_lambda_tol == 0.25 / math.sqrt(1000)
+    assert solve._options(SliceImage(), n_nodes=4000, **kw).stop_lambda_tol == 0.25 / math.sqrt(4000)
+
+
+def _collective_worker(rank, world, port, out):
+    _init(rank, world, port)
+    import ctypes as C
+    import time
+    from mgb_amd.sharded import _ABORT_KEY, _store, make_collective
+    coll = make_collective(dist, "cpu")
+    buf = np.array([1.0 + rank, 10.0 * (rank + 1)])
+    rc = coll(None, buf.ctypes.data_as(C.c_void_p), 2, 0, 0)                 # SUM, host buffer, in place
+    mx = np.array([float(rank)])
+    rc2 = coll(None, mx.ctypes.data_as(C.c_void_p), 1, 1, 0)                 # MAX
+    res = dict(rc=(rc, rc2), sum=buf.tolist(), max=mx.tolist())
+    dist.barrier()
+    # fail-fast: rank 1 "fails" (sets the abort key like ShardedSolver.solve_local does) and never enters the collective;
+    # rank 0 must come back from its all-reduce with an error instead of blocking
+    if rank == 1:
+        _store(dist).set(_ABORT_KEY, "1")
+        res["waited"] = 0.0
+    else:
+        t0 = time.monotonic()
+        rc3 = coll(None, buf.ctypes.data_as(C.c_void_p), 2, 0, 0)
+        res["waited"] = time.monotonic() - t0
+        res["rc_abort"] = rc3
+        res["err"] = str(coll.errors[-1]) if coll.errors else ""
+    out[rank] = res
+    # no barrier / destroy here: the group is poisoned by design after an abort
+
+
+def test_collective_sums_in_place_and_fails_fast_when_a_peer_aborts():
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_collective_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = dict(out)
+    for rank in range(world):
+        assert res[rank]["rc"] == (0, 0)
+        assert res[rank]["sum"] == [3.0, 30.0] and res[rank]["max"] == [1.0]
+    assert res[0]["rc_abort"] == 1 and "peer rank" in res[0]["err"]
+    assert res[0]["waited"] < 20.0
+
+
+@pytest.mark.gpu
+def test_sharded_config4_fem3d_L6_phase1_matches_single_rank():
+    """BASELINE configs[3] (`fem3d() Q1 p = 4, L = 6, domain-decomposed`) at full size from the default, infeasible start
+    -- phase I with box escalation, `_matched_t`, main ramp -- as ONE solve over two ranks sharing the device (the
+    rehearsal form of the 8-GPU configuration: this pipeline's build loop has one GPU).  Same z as the single-rank device
+    solve (1e-8, test/test_cuda.jl:51), same phase-I / main t-steps, Newton counts within 2 %."""
+    import mgb_amd as m
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_gpu_worker, args=(world, _free_port(), "fem3d_L6_config4", out), nprocs=world, join=True)
+        res = dict(out)
+    ref = m.mgb_solve(_problem("fem3d_L6_config4"))
+    assert ref.SOL_feasibility is not None
+    b = int(np.asarray(ref.SOL_main["its"]).sum())
+    bf = int(np.asarray(ref.SOL_feasibility["its"]).sum())
+    for rank in range(world):
+        r = res[rank]
+        assert r["feas"] is not None
+        assert np.abs(r["z"] - ref.z).max() < 1e-8
+        assert np.allclose(r["t"], ref.SOL_main["ts"])
+        assert abs(int(np.asarray(r["its"]).sum()) - b) <= max(3, 0.02 * b)
+        assert abs(int(np.asarray(r["feas"]).sum()) - bf) <= max(3, 0.02 * bf)
+    assert np.array_equal(res[0]["z"], res[1]["z"])
