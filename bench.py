@@ -181,7 +181,7 @@ def solver_roofline(kstats, chain, stats, hipevent_factor_us, hipevent_trisolve_
                    critical_path=dict(blocks=chain["pivot_blocks_on_critical_path"], mf_big_step_avg_us=step,
                                       model_us=chain["pivot_blocks_on_critical_path"] * step,
                                       note="device time of the step launches alone if every one of them sat on the chain; "
-                                           "the rest of factor_us is assembly (gather), the LDS-front levels and the one-pass Schur updates"))
+                                           "the rest of factor_us is assembly (gather) and the LDS-front levels"))
     else:
         out["source"] = "kernel-trace child pass unavailable: hipEvent stage timers only"
     return out

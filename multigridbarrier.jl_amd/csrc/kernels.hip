@@ -1034,12 +1034,16 @@ __global__ __launch_bounds__(256) void fill_kernel(double value, double* __restr
 // Row-owner gather: every structural nonzero of R'HR sums its contributions from the
 // element-block slab in a fixed order -- no atomics (the reference's CUDA path uses fp64
 // atomics, ext/MultiGridBarrierCUDAExt/block_ops.jl:229-249).
-__global__ __launch_bounds__(256) void gather_assemble_kernel(int64_t nnz, const int32_t* __restrict__ cptr,
+// qmap (optional): the positions to assemble -- the Newton loop forms the UPPER triangle only (`symmetric(H)` and the
+// factorization read nothing else, mf_analysis.cpp), nq of the nnz structural nonzeros.
+__global__ __launch_bounds__(256) void gather_assemble_kernel(int64_t nq, const int32_t* __restrict__ qmap,
+                                                              const int32_t* __restrict__ cptr,
                                                               const int32_t* __restrict__ cidx,
                                                               const double* __restrict__ slab,
                                                               double* __restrict__ Hval) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nnz) return;
+    const int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    const int64_t q = qmap ? qmap[qi] : qi;
     const int32_t beg = cptr[q], end = cptr[q + 1];
     if (end - beg <= 4) {              // a handful of element contributions: nothing to compensate
         double s = 0.0;
@@ -1086,13 +1090,15 @@ __global__ __launch_bounds__(256) void gather_shared_kernel(int64_t nshared, con
 
 // Long contribution lists (coarse levels: few unknowns, every element contributes): one wave per
 // structural nonzero, lanes stride over the list, fixed-order shuffle reduction.
-__global__ __launch_bounds__(256) void gather_assemble_wave_kernel(int64_t nnz, const int32_t* __restrict__ cptr,
+__global__ __launch_bounds__(256) void gather_assemble_wave_kernel(int64_t nq, const int32_t* __restrict__ qmap,
+                                                                   const int32_t* __restrict__ cptr,
                                                                    const int32_t* __restrict__ cidx,
                                                                    const double* __restrict__ slab,
                                                                    double* __restrict__ Hval) {
     const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= nnz) return;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const int64_t q = qmap ? qmap[qi] : qi;
     DSum a;
     for (int32_t t = cptr[q] + lane; t < cptr[q + 1]; t += 64) a.add(slab[cidx[t]]);
     dsum_wave_reduce(a);
@@ -1102,16 +1108,18 @@ __global__ __launch_bounds__(256) void gather_assemble_wave_kernel(int64_t nnz, 
 // Very long lists (the coarsest levels: a handful of nonzeros, each summing every element): one wave per
 // (nonzero, chunk of the list), then one wave per nonzero over the chunk sums.  Fixed chunking and fixed
 // shuffle trees: the result does not depend on scheduling.
-__global__ __launch_bounds__(256) void gather_assemble_chunk_kernel(int64_t nnz, int32_t ch, int32_t nchunk,
+__global__ __launch_bounds__(256) void gather_assemble_chunk_kernel(int64_t nq, const int32_t* __restrict__ qmap, int32_t ch,
+                                                                    int32_t nchunk,
                                                                     const int32_t* __restrict__ cptr,
                                                                     const int32_t* __restrict__ cidx,
                                                                     const double* __restrict__ slab,
                                                                     double* __restrict__ part) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= nnz * nchunk) return;
-    const int64_t q = w / nchunk;
-    const int32_t c = (int32_t)(w - q * nchunk);
+    if (w >= nq * nchunk) return;
+    const int64_t qi = w / nchunk;
+    const int32_t c = (int32_t)(w - qi * nchunk);
+    const int64_t q = qmap ? qmap[qi] : qi;
     const int32_t beg = cptr[q] + c * ch, end = min(cptr[q + 1], beg + ch);
     DSum a;
     for (int32_t t = beg + lane; t < end; t += 256) {      // four loads in flight per lane
@@ -1126,15 +1134,15 @@ __global__ __launch_bounds__(256) void gather_assemble_chunk_kernel(int64_t nnz,
     if (lane == 0) { part[2 * w] = a.s; part[2 * w + 1] = a.c; }
 }
 
-__global__ __launch_bounds__(256) void gather_assemble_chunk_reduce(int64_t nnz, int32_t nchunk, const double* __restrict__ part,
-                                                                    double* __restrict__ Hval) {
+__global__ __launch_bounds__(256) void gather_assemble_chunk_reduce(int64_t nq, const int32_t* __restrict__ qmap, int32_t nchunk,
+                                                                    const double* __restrict__ part, double* __restrict__ Hval) {
     const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= nnz) return;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
     DSum a;
-    for (int32_t c = lane; c < nchunk; c += 64) a.merge(part[2 * (q * nchunk + c)], part[2 * (q * nchunk + c) + 1]);
+    for (int32_t c = lane; c < nchunk; c += 64) a.merge(part[2 * (qi * nchunk + c)], part[2 * (qi * nchunk + c) + 1]);
     dsum_wave_reduce(a);
-    if (lane == 0) Hval[q] = a.value();
+    if (lane == 0) Hval[qmap ? qmap[qi] : qi] = a.value();
 }
 
 // General (coarse) levels: one wave per element computes the projected block
@@ -1155,7 +1163,7 @@ __global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P)
     for (int a = 0; a < nu; ++a) {
         const int32_t oa = P.ecol_ptr[e * nu + a], ca = P.ecol_ptr[e * nu + a + 1] - oa;
         const double* pa = P.panels + (int64_t)p * oa;
-        for (int b = 0; b < nu; ++b) {
+        for (int b = P.upper_only ? a : 0; b < nu; ++b) {        // upper_only: block pairs below the diagonal are never read
             const int32_t ob = P.ecol_ptr[e * nu + b], cb = P.ecol_ptr[e * nu + b + 1] - ob;
             const double* pb = P.panels + (int64_t)p * ob;
             const bool tr = a > b;
@@ -1172,6 +1180,7 @@ __global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int t = lane; t < ca * cb; t += 64) {
                 const int ia = t % ca, ib = t / ca;
+                if (P.upper_only && a == b && ia > ib) continue;
                 double acc = 0.0;
                 for (int rr = 0; rr < p; ++rr) acc += pa[rr + p * ia] * tmp[rr + p * ib];
                 out[(oa - base + ia) + (int64_t)ct * (ob - base + ib)] = acc;
@@ -1388,6 +1397,19 @@ __global__ __launch_bounds__(256) void panel_project_staged_kernel(const PanelPa
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double* out = P.slab + P.eoff[e];
+    if (P.upper_only) {                     // the Newton loop reads entries i <= j only (the element's columns are sorted)
+        for (int t = lane; t < ct * (ct + 1) / 2; t += 64) {
+            int j = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while ((j + 1) * (j + 2) / 2 <= t) ++j;
+            while (j * (j + 1) / 2 > t) --j;
+            const int i = t - j * (j + 1) / 2;
+            const int a = sl[i];
+            double acc = 0.0;
+            for (int rr = 0; rr < p; ++rr) acc += Pl[rr + p * i] * Tl[(a * p + rr) + nrow * j];
+            out[i + ct * j] = acc;
+        }
+        return;
+    }
     for (int t = lane; t < ct * ct; t += 64) {
         int j = (int)(((float)t + 0.5f) * inv_ct);
         if (j * ct > t) --j;
@@ -1760,17 +1782,20 @@ void launch_fill(double value, double* y, int64_t len, hipStream_t st) {
 }
 
 void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,
-                            double* Hval, bool long_lists, hipStream_t st, int32_t chunk, int32_t nchunk, double* part) {
+                            double* Hval, bool long_lists, hipStream_t st, int32_t chunk, int32_t nchunk, double* part,
+                            const int32_t* qmap, int64_t nq) {
     if (nnz == 0) return;
+    if (!qmap) nq = nnz;
+    if (nq == 0) return;
     if (long_lists && nchunk > 1) {
-        hipLaunchKernelGGL(gather_assemble_chunk_kernel, dim3((unsigned)((nnz * nchunk + 3) / 4)), dim3(256), 0, st, nnz, chunk,
+        hipLaunchKernelGGL(gather_assemble_chunk_kernel, dim3((unsigned)((nq * nchunk + 3) / 4)), dim3(256), 0, st, nq, qmap, chunk,
                            nchunk, cptr, cidx, slab, part);
-        hipLaunchKernelGGL(gather_assemble_chunk_reduce, dim3((unsigned)((nnz + 3) / 4)), dim3(256), 0, st, nnz, nchunk, part, Hval);
+        hipLaunchKernelGGL(gather_assemble_chunk_reduce, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, nq, qmap, nchunk, part, Hval);
     } else if (long_lists)
-        hipLaunchKernelGGL(gather_assemble_wave_kernel, dim3((unsigned)((nnz + 3) / 4)), dim3(256), 0, st, nnz, cptr,
+        hipLaunchKernelGGL(gather_assemble_wave_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, nq, qmap, cptr,
                            cidx, slab, Hval);
     else
-        hipLaunchKernelGGL(gather_assemble_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, cptr,
+        hipLaunchKernelGGL(gather_assemble_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, qmap, cptr,
                            cidx, slab, Hval);
     MGB_HIP_CHECK(hipGetLastError());
 }

@@ -126,9 +126,10 @@ void launch_fill(double value, double* y, int64_t len, hipStream_t st);       //
 // sums of the structural nonzeros with other than one contribution (direct-value levels), in list order
 void launch_gather_shared(int64_t nshared, const int32_t* sh_q, const int32_t* cptr, const int32_t* cidx, const double* slab,
                           double* out, hipStream_t st);
+// qmap / nq (optional): assemble only the listed positions (the Newton loop: the upper triangle, all the solver reads)
 void launch_gather_assemble(int64_t nnz, const int32_t* cptr, const int32_t* cidx, const double* slab,
                             double* Hval, bool long_lists, hipStream_t st, int32_t chunk = 0, int32_t nchunk = 0,
-                            double* part = nullptr);     // nchunk > 1: two-stage sums of very long lists
+                            double* part = nullptr, const int32_t* qmap = nullptr, int64_t nq = 0);     // nchunk > 1: two-stage sums of very long lists
 
 // general (coarse) levels: slab_e = [panel_0 .. panel_{nu-1}]' * Hel_e * [panel_0 .. panel_{nu-1}]
 // (c_tot x c_tot, column-major, at eoff[e]); the structural nonzeros then gather from the slab.
@@ -141,6 +142,7 @@ struct PanelParams {
     const double* hel;
     double* slab;
     int32_t cmax;                 // largest per-(element, state) column count
+    int32_t upper_only;           // project only the entries (i <= j) of the element's block: what an upper-triangle gather reads
 };
 void launch_panel_project(const PanelParams& P, hipStream_t st);
 // small coarse levels with wide supports: element streams x chunks of the packed upper triangle of H

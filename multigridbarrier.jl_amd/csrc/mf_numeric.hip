@@ -1436,158 +1436,16 @@ constexpr int BIG_INV_MAX_M = 7000;     // work vectors of the single-workgroup 
 constexpr int BIGI_THREADS = 1024;
 
 
-// Blocked LDL' of the 32 x 32 block in Dn (row-major lower triangle, in LDS) by the whole workgroup.
-// Every cross-thread hand-off on this chip costs several hundred cycles (measured: ~600 cycles per
-// column for a one-column-at-a-time factorization, whether one wave keeps the rows in registers or eight
-// half-waves share the columns), so the pivot recurrence runs four columns at a time inside ONE lane:
-//   serial   lane 0: LDL' of the 4 x 4 diagonal block, its unit-lower inverse W4 and 1/d    (registers only)
-//   phase A  rows below the block: s = a W4', l = s / d; l is final, (s, l) go to the panel buffers
-//   phase B  trailing update  a(r, c) -= sum_k s(r, k) l(c, k);  the next 4 x 4 diagonal block is taken by
-//            ten lanes of wave 0, and lane 0 factors it at once while the other waves finish the update
-// -> two workgroup barriers per four columns.  On return Dn holds the strictly lower unit factor (zeros
-// elsewhere, identity beyond nb), dq the pivots (1 beyond nb).  Every thread of the workgroup must call this.
 #include "ldlt32.hpp"
 
-__device__ __forceinline__ void block_ldlt32_b4(double (*Dn)[NB + 1], double* dq, int nb, int tid, double* Wb /* [2][16] */,
-                                                double (*Sp)[4], double (*Lp)[4], int32_t* __restrict__ status) {
-    const int r = tid & 31, cg = tid >> 5;
-    // identity padding beyond nb keeps the 4 x 4 recurrences free of special cases
-    if (tid < NB && tid >= nb) Dn[tid][tid] = 1.0;
-    __syncthreads();
-    auto serial = [&](int cb, int buf) {      // lane 0 only: factor the diagonal block at cb, publish W4 / d / 1/d and L11
-        Blk4 B;
-        double l[6];
-        const bool bad = ldlt4_serial(Dn[cb][cb], Dn[cb + 1][cb], Dn[cb + 1][cb + 1], Dn[cb + 2][cb], Dn[cb + 2][cb + 1],
-                                      Dn[cb + 2][cb + 2], Dn[cb + 3][cb], Dn[cb + 3][cb + 1], Dn[cb + 3][cb + 2],
-                                      Dn[cb + 3][cb + 3], B, l);
-        if (bad && status) atomicOr(status, 1);
-        double* w = Wb + 16 * buf;
-        w[0] = B.w10; w[1] = B.w20; w[2] = B.w21; w[3] = B.w30; w[4] = B.w31; w[5] = B.w32;
-        w[6] = B.i0; w[7] = B.i1; w[8] = B.i2; w[9] = B.i3;
-        dq[cb] = B.d0; dq[cb + 1] = B.d1; dq[cb + 2] = B.d2; dq[cb + 3] = B.d3;
-        Dn[cb + 1][cb] = l[0]; Dn[cb + 2][cb] = l[1]; Dn[cb + 2][cb + 1] = l[2];
-        Dn[cb + 3][cb] = l[3]; Dn[cb + 3][cb + 1] = l[4]; Dn[cb + 3][cb + 2] = l[5];
-    };
-    if (tid == 0) serial(0, 0);
-    __syncthreads();
-#pragma unroll 1
-    for (int b = 0; b < NB / 4; ++b) {
-        const int cb = 4 * b, cn = cb + 4;
-        const double* w = Wb + 16 * (b & 1);
-        // phase A: panel rows
-        if (tid < NB && tid >= cn) {
-            const double a0 = Dn[tid][cb], a1 = Dn[tid][cb + 1], a2 = Dn[tid][cb + 2], a3 = Dn[tid][cb + 3];
-            const double s0 = a0;
-            const double s1 = a1 + a0 * w[0];
-            const double s2 = a2 + a0 * w[1] + a1 * w[2];
-            const double s3 = a3 + a0 * w[3] + a1 * w[4] + a2 * w[5];
-            const double l0 = s0 * w[6], l1 = s1 * w[7], l2 = s2 * w[8], l3 = s3 * w[9];
-            Dn[tid][cb] = l0; Dn[tid][cb + 1] = l1; Dn[tid][cb + 2] = l2; Dn[tid][cb + 3] = l3;
-            Sp[tid][0] = s0; Sp[tid][1] = s1; Sp[tid][2] = s2; Sp[tid][3] = s3;
-            Lp[tid][0] = l0; Lp[tid][1] = l1; Lp[tid][2] = l2; Lp[tid][3] = l3;
-        }
-        __syncthreads();
-        if (cn >= NB) break;
-        // phase B: next diagonal block first (ten lanes of wave 0, then lane 0 alone), trailing update elsewhere
-        if (tid < 10) {
-            const int rr = tid < 1 ? 0 : (tid < 3 ? 1 : (tid < 6 ? 2 : 3));
-            const int cc = tid - rr * (rr + 1) / 2;
-            const int R = cn + rr, C = cn + cc;
-            Dn[R][C] -= Sp[R][0] * Lp[C][0] + Sp[R][1] * Lp[C][1] + Sp[R][2] * Lp[C][2] + Sp[R][3] * Lp[C][3];
-        }
-        if (tid < 64) wave_sync();
-        if (tid == 0) serial(cn, (b + 1) & 1);
-        if (r >= cn + 4) {                      // rows below the next diagonal block
-            for (int c = cn + cg; c <= r; c += 8)
-                Dn[r][c] -= Sp[r][0] * Lp[c][0] + Sp[r][1] * Lp[c][1] + Sp[r][2] * Lp[c][2] + Sp[r][3] * Lp[c][3];
-        }
-        __syncthreads();
-    }
-    // strictly lower L only: clear the diagonal and everything above it
-    for (int i = tid; i < NB * NB; i += 256) {
-        const int rr = i / NB, cc = i % NB;
-        if (cc >= rr || rr >= nb) Dn[rr][cc] = 0.0;
-    }
-    __syncthreads();
-}
-
-// The shipped 32 x 32 LDL': one wave, matrix-core updates (ldlt32.hpp); -DMGB_LDLT32_B4 selects the 4 x 4-blocked workgroup form
-// (whose 3 KB of LDS scratch kept mf_big_step at two workgroups per compute unit: without it three fit).
-#ifdef MGB_LDLT32_B4
-#define MGB_LDLT_SCRATCH_DECL __shared__ __attribute__((aligned(16))) double colbuf[4 * NB]; __shared__ double Sp4[NB][4], Lp4[NB][4];
-#define MGB_LDLT_SCRATCH colbuf, Sp4, Lp4
-#else
-#define MGB_LDLT_SCRATCH_DECL
-#define MGB_LDLT_SCRATCH nullptr, nullptr, nullptr
-#endif
-__device__ __forceinline__ void block_ldlt32(double (*Dn)[NB + 1], double* dq, int nb, int tid, double* Wb, double (*Sp)[4],
-                                             double (*Lp)[4], int32_t* __restrict__ status) {
-#ifdef MGB_LDLT32_B4
-    block_ldlt32_b4(Dn, dq, nb, tid, Wb, Sp, Lp, status);
-#else
-    (void)Wb; (void)Sp; (void)Lp;
+// The 32 x 32 LDL' of the pivot chain and the inverse of its factor: one wave each, every product on the matrix cores
+// (ldlt32.hpp; the 256-thread forms of round 2 -- 4 x 4-blocked LDL', seven-barrier recursive doubling -- were removed in
+// round 4: no build selected them).
+__device__ __forceinline__ void block_ldlt32(double (*Dn)[NB + 1], double* dq, int nb, int tid, int32_t* __restrict__ status) {
     block_ldlt32_mfma(Dn, dq, nb, tid, status);
-#endif
 }
-
-// W = L^{-1} for the unit lower triangular 32 x 32 L in Ls (strictly lower part, row-major), all 256
-// threads: 4 x 4 diagonal blocks in closed form, then three doubling steps
-//   W21 = -W22 (L21 W11)
-// through a 16 x 16 temporary.  Wv receives W with unit diagonal and a zero upper triangle.
-// Every thread of the workgroup must call this (7 barriers).
-__device__ __forceinline__ void block_inverse32(const double (*Ls)[NB + 1], double (*Wv)[NB + 1], double (*Tm)[17],
-                                                int tid) {
-    for (int i = tid; i < NB * NB; i += 256) Wv[i / NB][i % NB] = (i / NB == i % NB) ? 1.0 : 0.0;
-    __syncthreads();
-    if (tid < NB / 4) {
-        const int o = 4 * tid;
-        const double l21 = Ls[o + 1][o], l31 = Ls[o + 2][o], l32 = Ls[o + 2][o + 1];
-        const double l41 = Ls[o + 3][o], l42 = Ls[o + 3][o + 1], l43 = Ls[o + 3][o + 2];
-        Wv[o + 1][o] = -l21;
-        Wv[o + 2][o + 1] = -l32;
-        Wv[o + 3][o + 2] = -l43;
-        Wv[o + 2][o] = l32 * l21 - l31;
-        Wv[o + 3][o + 1] = l43 * l32 - l42;
-        Wv[o + 3][o] = l42 * l21 + l43 * (l31 - l32 * l21) - l41;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 4; s < NB; s *= 2) {
-        const int ss = s * s;
-        const bool on = tid < 16 * s;
-        const int pr = tid / ss, e = tid % ss, i = e % s, j = e / s;
-        const int base = 2 * s * pr;
-        if (on) {       // structural zeros (W11 upper, W22 upper) make the fixed trip count exact
-            double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-            for (int a = 0; a < s; a += 2) {
-                t0 += Ls[base + s + i][base + a] * Wv[base + a][base + j];
-                t1 += Ls[base + s + i][base + a + 1] * Wv[base + a + 1][base + j];
-            }
-            Tm[pr * s + i][j] = t0 + t1;
-        }
-        __syncthreads();
-        if (on) {
-            double w0 = 0.0, w1 = 0.0;
-#pragma unroll
-            for (int a = 0; a < s; a += 2) {
-                w0 += Wv[base + s + i][base + s + a] * Tm[pr * s + a][j];
-                w1 += Wv[base + s + i][base + s + a + 1] * Tm[pr * s + a + 1][j];
-            }
-            Wv[base + s + i][base + j] = -(w0 + w1);
-        }
-        __syncthreads();
-    }
-}
-
-// The shipped inverse: one wave, every product on the matrix cores (ldlt32.hpp: 2.9 k cycles against 3.9 k);
-// -DMGB_INV32_OLD selects the 256-thread recursive doubling above.
 __device__ __forceinline__ void block_inverse32_sel(const double (*Ls)[NB + 1], double (*Wv)[NB + 1], double (*Tm)[17], int tid) {
-#ifdef MGB_INV32_OLD
-    block_inverse32(Ls, Wv, Tm, tid);
-#else
     block_inverse32_mfma(Ls, Wv, Tm, tid);
-#endif
 }
 
 // S = A W' for a 64-row slice held raw in P[c][rr] (LDS, overwritten in place); wave w owns rows
@@ -1631,10 +1489,10 @@ __global__ __launch_bounds__(256, 3) void mf_big_step(const FrontDev* __restrict
     __shared__ double Dn[NB][NB + 1];
     __shared__ double Tm[16][17];
     __shared__ double dq[NB], rdq[NB];
-    MGB_LDLT_SCRATCH_DECL
     __shared__ double Pa[NB][ST + 1];
     __shared__ double Pb[NB][ST + 1];
-    const FrontDev F = fr[first + blockIdx.y];
+    const FrontDev F = fr[first + blockIdx.y];      // (as kernel arguments for launches of few fronts: the kernel sits at its
+                                                      // 168-register cap and spilled, 6 % slower end to end: measured in round 4)
     const int m = F.m, k = F.k;
     if (j0 >= k) return;
     const int nb = min(NB, k - j0);
@@ -1696,7 +1554,7 @@ __global__ __launch_bounds__(256, 3) void mf_big_step(const FrontDev* __restrict
             Dn[rr][c] = (rr >= c && rr < nb) ? W[(j0 + rr) + (int64_t)(j0 + c) * m] : 0.0;
         }
         __syncthreads();
-        block_ldlt32(Dn, dq, nb, tid, MGB_LDLT_SCRATCH, is_la ? status : nullptr);
+        block_ldlt32(Dn, dq, nb, tid, is_la ? status : nullptr);
         block_inverse32_sel(Dn, Wv, Tm, tid);
     } else {
         for (int i = tid; i < NB * NB; i += 256) {
@@ -1778,7 +1636,7 @@ __global__ __launch_bounds__(256, 3) void mf_big_step(const FrontDev* __restrict
         __builtin_amdgcn_sched_barrier(0);
         if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[32] = clock64(); g_probe[36] = wall_clock64(); }
         __builtin_amdgcn_sched_barrier(0);
-        block_ldlt32(Dn, dq, nbn, tid, MGB_LDLT_SCRATCH, nullptr);
+        block_ldlt32(Dn, dq, nbn, tid, nullptr);
         __builtin_amdgcn_sched_barrier(0);
         if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[33] = clock64(); g_probe[37] = wall_clock64(); }
         __builtin_amdgcn_sched_barrier(0);
@@ -1788,20 +1646,14 @@ __global__ __launch_bounds__(256, 3) void mf_big_step(const FrontDev* __restrict
         if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[38] = clock64(); g_probe[44] = wall_clock64(); }
         __builtin_amdgcn_sched_barrier(0);
 #endif
-#ifdef MGB_LDLT32_FUSED_INV
-        block_ldlt32_inv_mfma(Dn, dq, nbn, tid, Wv, status);
-#else
-        block_ldlt32(Dn, dq, nbn, tid, MGB_LDLT_SCRATCH, status);
-#endif
+        block_ldlt32(Dn, dq, nbn, tid, status);
 #ifdef MGB_STEP_PROBE
         __builtin_amdgcn_sched_barrier(0);
         if (is_la && blockIdx.y == 0 && tid == 0 && j0 == 64 && gridDim.y == 1 && F.k > 400) { g_probe[39] = clock64(); g_probe[45] = wall_clock64(); }
         __builtin_amdgcn_sched_barrier(0);
 #endif
         PROBE(5);
-#ifndef MGB_LDLT32_FUSED_INV
         block_inverse32_sel(Dn, Wv, Tm, tid);
-#endif
         PROBE(6);
         for (int i = tid; i < NB * NB; i += 256) {        // slot: diagonal d, strictly lower W (column-major)
             const int rr = i % NB, c = i / NB;
@@ -1885,7 +1737,6 @@ __global__ __launch_bounds__(256) void mf_big_diag0(const FrontDev* __restrict__
     __shared__ double Dn[NB][NB + 1];
     __shared__ double Tm[16][17];
     __shared__ double dq[NB];
-    MGB_LDLT_SCRATCH_DECL
     const FrontDev F = fr[first + blockIdx.x];
     const int m = F.m, nb = min(NB, F.k), tid = threadIdx.x;
     const double* W = arena + F.F_off;
@@ -1894,7 +1745,7 @@ __global__ __launch_bounds__(256) void mf_big_diag0(const FrontDev* __restrict__
         Dn[rr][c] = (rr >= c && rr < nb) ? W[rr + (int64_t)c * m] : 0.0;
     }
     __syncthreads();
-    block_ldlt32(Dn, dq, nb, tid, MGB_LDLT_SCRATCH, status);
+    block_ldlt32(Dn, dq, nb, tid, status);
     block_inverse32_sel(Dn, Wv, Tm, tid);
     double* slot = dscr + (int64_t)blockIdx.x * 2 * (NB * NB);
     for (int i = tid; i < NB * NB; i += 256) {
@@ -1934,8 +1785,7 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
         __shared__ double Dn[NB][NB + 1];
         __shared__ double Tm[16][17];
         __shared__ double dq[NB];
-        MGB_LDLT_SCRATCH_DECL
-        __shared__ int32_t inv0[GATHER_MAX_CHILD][NB];
+            __shared__ int32_t inv0[GATHER_MAX_CHILD][NB];
         const int tid = threadIdx.x, nch = F.nchild, nb = min(NB, F.k);
         // the first batch of A entries of the block (cp -> a_dst / a_src -> Hval: three dependent loads) is requested before
         // the children's chain (children -> descriptor -> rel -> arena: four more) instead of after it
@@ -1988,7 +1838,7 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
             }
         }
         __syncthreads();
-        block_ldlt32(Dn, dq, nb, tid, MGB_LDLT_SCRATCH, status);
+        block_ldlt32(Dn, dq, nb, tid, status);
         block_inverse32_sel(Dn, Wv, Tm, tid);
         double* slot = dscr + (int64_t)blockIdx.y * 2 * (NB * NB);
         for (int i = tid; i < NB * NB; i += 256) {
@@ -2027,7 +1877,7 @@ __global__ __launch_bounds__(256) void mf_big_gather(const FrontDev* __restrict_
             const int jc = ch < nch ? inv[ch * mstride + c] : -1;
             colbase[ch] = jc >= 0 ? cU[ch] + (int64_t)jc * cM[ch] : -1;
         }
-        for (int r = c + lane; r < m; r += 128) {  // two rows per lane in flight
+        for (int r = c + lane; r < m; r += 128) {  // two rows per lane in flight (four: 2 % slower end to end, measured in round 4)
             const int r1 = r + 64;
             double u0[GATHER_MAX_CHILD], u1[GATHER_MAX_CHILD];
 #pragma unroll
@@ -2380,10 +2230,6 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     opt.protect_peeled = protect_peeled;
     opt.top = top;
     opt.ntop = ntop;
-    // tuning overrides (defaults are the measured best on MI355X)
-    if (const char* e = getenv("MGBHIP_LEAF")) opt.leaf_size = atoi(e);
-    if (const char* e = getenv("MGBHIP_SEPW")) opt.sep_weight = atof(e);
-    if (const char* e = getenv("MGBHIP_MERGE")) opt.merge_max_m = atoi(e);
     if (const char* e = getenv("MGBHIP_NO_GEO"); e && e[0] == '1') coords = nullptr;
     opt.border = true;          // every system is factored bordered (mf_analysis.hpp): the Newton solve needs no forward sweep
     mf_analyze(n, rowptr, colidx, opt, plan, coords, dim);
@@ -2418,11 +2264,7 @@ void MfSolver::analyze(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
 
     // dynamic LDS above 64 KB needs an explicit opt-in; fall back to the 64 KB classes if refused
     lds_cap = 88;
-    if (hipFuncSetAttribute((const void*)mf_factor_small<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (128 * 128 + 16 * 128) * 8) == hipSuccess &&
-        hipFuncSetAttribute((const void*)mf_factor_small<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (128 * 128 + 16 * 128) * 8) == hipSuccess &&
-        hipFuncSetAttribute((const void*)mf_factor_small<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)mf_factor_small<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (128 * 128 + 16 * 128) * 8) == hipSuccess)
         lds_cap = 128;
     else
@@ -2690,11 +2532,7 @@ bool MfSolver::launch_big_assemble(const MfLaunch& L, dim3 ga, const double* d_v
                                    bool with_diag) {
     const size_t lds = (size_t)L.max_child * (size_t)L.max_m * sizeof(int32_t);
     if (L.max_child >= 1 && L.max_child <= GATHER_MAX_CHILD && lds <= 40 * 1024) {
-        // few fronts: one destination column per wave (a level with one to eight fronts is a latency chain: twice the
-        // workgroups halve the columns each wave walks through); many fronts: two per wave, half the per-workgroup set-up
-        static const int ct_few = [] { const char* e = getenv("MGBHIP_GATHER_CT"); return e ? atoi(e) : 4; }();
-        const int ct = (L.count <= 8 && ct_few >= 4 && ct_few <= CT) ? ct_few : CT;
-        ga.x = (unsigned)((L.max_m + ct - 1) / ct);
+        const int ct = CT;                 // (one column per wave on levels with few fronts, ct = 4: no gain, measured in round 4)
         if (with_diag) ga.x += 1;          // the diagonal-block workgroup
         hipLaunchKernelGGL(mf_big_gather, ga, dim3(256), lds, st, cur_fr, L.first, d_children.p, d_rel.p, a_src_p,
                            cur_adst, cur_acol, d_values, d_arena.p, L.max_m, d_dscr.p, d_status.p, with_diag ? 1 : 0, ct);
@@ -2758,20 +2596,16 @@ void MfSolver::factor(const double* d_values, hipStream_t st, StageTimers* timer
                                        a_src_p, cur_adst, d_values, d_arena.p, d_status.p);
                 }
             } else if (L.cls) {
-                static const int nbt_mid = [] { const char* e = getenv("MGBHIP_NBT"); return e ? atoi(e) : 8; }();
-                static const int thr_mid = [] { const char* e = getenv("MGBHIP_SMALL_THREADS"); return e ? atoi(e) : 256; }();
-                const int threads = L.cls <= 16 ? 64 : (L.cls <= 32 ? 128 : (L.cls <= 64 ? thr_mid : 256));
-                const int nbt = L.cls <= 16 ? 8 : std::min(nbt_mid, 16);    // 32-column LDS panels do not fit beside a 128 x 128 front
-                const int nbt_alloc = nbt <= 8 ? 8 : (nbt <= 16 ? 16 : 32);
+                // 8-column LDS panels (16- and 32-column ones were measured slower in round 3 and removed in round 4)
+                const int threads = L.cls <= 16 ? 64 : (L.cls <= 32 ? 128 : 256);
                 const bool packed = L.cls >= 88;
-                const size_t lds = (size_t)((packed ? L.cls * (L.cls + 1) / 2 : L.cls * L.cls) + nbt_alloc * L.cls) * sizeof(double);    // front + scaled panel
-#define MGB_LAUNCH_SMALL(NBTV, PK)                                                                                          \
-    hipLaunchKernelGGL((mf_factor_small<NBTV, PK>), dim3(L.count), dim3(threads), lds, st, cur_fr, L.first, d_children.p, \
-                       d_rel.p, a_src_p, cur_adst, d_values, d_arena.p, d_status.p)
-                if (nbt <= 8) { if (packed) MGB_LAUNCH_SMALL(8, true); else MGB_LAUNCH_SMALL(8, false); }
-                else if (nbt <= 16) { if (packed) MGB_LAUNCH_SMALL(16, true); else MGB_LAUNCH_SMALL(16, false); }
-                else { if (packed) MGB_LAUNCH_SMALL(32, true); else MGB_LAUNCH_SMALL(32, false); }
-#undef MGB_LAUNCH_SMALL
+                const size_t lds = (size_t)((packed ? L.cls * (L.cls + 1) / 2 : L.cls * L.cls) + 8 * L.cls) * sizeof(double);    // front + scaled panel
+                if (packed)
+                    hipLaunchKernelGGL((mf_factor_small<8, true>), dim3(L.count), dim3(threads), lds, st, cur_fr, L.first, d_children.p,
+                                       d_rel.p, a_src_p, cur_adst, d_values, d_arena.p, d_status.p);
+                else
+                    hipLaunchKernelGGL((mf_factor_small<8, false>), dim3(L.count), dim3(threads), lds, st, cur_fr, L.first, d_children.p,
+                                       d_rel.p, a_src_p, cur_adst, d_values, d_arena.p, d_status.p);
             } else if (L.iface) {
                 // assemble this rank's contribution, sum over ranks, then factor the complete front (every rank the same)
                 MGB_REQUIRE((bool)iface_reduce, "MfSolver: interface front without a reduction hook");

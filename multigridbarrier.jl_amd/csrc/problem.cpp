@@ -406,7 +406,7 @@ void mgbhip_problem::ensure_plan(int level) {
         L.acc_chunk = (int32_t)chunk;
         // wide coarse supports only (3-D hierarchies): many contributions per entry, few enough
         // elements per stream; narrow supports are faster through slab + gather
-        static const int64_t acc_ne_max = [] { const char* e = getenv("MGBHIP_ACC_NE_MAX"); return e ? atoll(e) : 65536ll; }();
+        constexpr int64_t acc_ne_max = 65536;
         L.acc = !selection && m > 0 && m <= ACC_MAX_M && room > 0 && nsplit <= 4 && NE <= acc_ne_max && slab_est >= 16 * mt &&
                 panel_accumulate_fits(pp, nu, (int)ctmax);
         if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
@@ -613,6 +613,18 @@ void mgbhip_problem::ensure_plan(int level) {
             L.gather_nchunk = (int32_t)((maxlen + L.gather_chunk - 1) / L.gather_chunk);
             L.gather_part.alloc(2 * (size_t)L.nnz * (size_t)L.gather_nchunk);      // (sum, carried error) per chunk
         }
+    }
+    if (!selection && !L.acc && L.nnz > 0) {
+        // positions of the upper triangle: `symmetric(H)` (src/newton.jl:253) and the factorization read nothing else, so the
+        // Newton loop projects and gathers only those (half the slab stores, half the gather traffic)
+        std::vector<int32_t> up;
+        up.reserve((size_t)(L.nnz / 2 + m));
+        for (int64_t i = 0; i < m; ++i)
+            for (int32_t q = L.hHptr[i]; q < L.hHptr[i + 1]; ++q)
+                if (L.hHcol[q] >= i) up.push_back(q);
+        L.nup = (int64_t)up.size();
+        L.upq.upload(up, st);
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
     }
     if (!selection) {
         // dense R panels per (element, state): p x c, column-major
@@ -893,6 +905,10 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
             PP.p = p; PP.nu = nu; PP.N = N;
             PP.ecol_ptr = L.ecol_ptr.p; PP.panels = L.panels.p; PP.eoff = L.eoff.p;
             PP.hel = d_hel.p; PP.slab = L.slab.p; PP.cmax = L.cmax;
+            // Newton loop (materialize = false with a right-hand side): only the upper triangle of H is formed
+            static const bool full_h = [] { const char* e = getenv("MGBHIP_FULL_COARSE_H"); return e && e[0] == '1'; }();
+            const bool upper = !materialize && rhs != nullptr && L.nup > 0 && !L.acc && !full_h;
+            PP.upper_only = upper ? 1 : 0;
             if (L.acc) {
                 launch_panel_accumulate(PP, L.ecols.p, (int32_t)L.m, L.acc_waves, L.acc_split, L.acc_chunk, L.acc_ctmax,
                                         L.acc_copies.p, L.Hval.p, st);
@@ -900,7 +916,8 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
                 // staged variant while four workgroups still fit a CU (narrow supports: 2-D hierarchies)
                 if (panel_accumulate_lds(p, nu, L.acc_ctmax) <= 40 * 1024) launch_panel_project_staged(PP, L.acc_ctmax, st);
                 else launch_panel_project(PP, st);
-                launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st, L.gather_chunk, L.gather_nchunk, L.gather_part.p);
+                launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st, L.gather_chunk, L.gather_nchunk, L.gather_part.p,
+                                       upper ? L.upq.p : nullptr, upper ? L.nup : 0);
             }
         }
     }

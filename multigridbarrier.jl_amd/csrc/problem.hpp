@@ -58,6 +58,8 @@ struct Level {
     bool long_lists = false;
     int32_t gather_chunk = 0, gather_nchunk = 0;   // very long lists: two-stage gather (chunk length, chunks per list)
     DevBuf<double> gather_part;
+    DevBuf<int32_t> upq;                  // general (projected) levels: CSR positions with col >= row, what the Newton loop assembles
+    int64_t nup = 0;
     int64_t nnz = 0;
     // dense (spectral) levels: DR = [D_k R_{state(k)}]_k stacked ((nD*n) x m) and W = Ybar * DR
     DevBuf<double> denseDR, denseW;

@@ -1,0 +1,44 @@
+"""The A/B switches of the symbolic analysis / launch plan that have no other test (tools/README.md, switch table):
+MGBHIP_NO_GEO (BFS level-set bisection instead of geometric nested dissection), MGBHIP_NO_MERGE_GROUPS (no folding of
+straggler launch groups), MGBHIP_NO_PACKED_LEAVES (square leaf fronts).  Each changes the elimination order or the launch
+grouping, never the mathematics: a complete solve under each switch must reproduce the default solve (z to 1e-10 relative,
+Newton counts within +-3).  The switches are read once per process, hence the worker processes."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CODE = ("import sys, json; sys.path.insert(0, %r)\n"
+        "import numpy as np, mgb_amd as m\n"
+        "sol = m.mgb_solve(m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 6)), p=1.5))\n"
+        "np.save(sys.argv[1], sol.z); print(json.dumps(int(sol.SOL_main['its'].sum())))\n") % ROOT
+
+
+def _solve(tmp_path, tag, env):
+    out = str(tmp_path / f"{tag}.npy")
+    r = subprocess.run([sys.executable, "-c", CODE, out], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.load(out), json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_plan_switches_reproduce_the_default_solve(tmp_path):
+    z0, its0 = _solve(tmp_path, "default", {})
+    for sw in ("MGBHIP_NO_GEO", "MGBHIP_NO_MERGE_GROUPS", "MGBHIP_NO_PACKED_LEAVES"):
+        z, its = _solve(tmp_path, sw, {sw: "1"})
+        assert np.abs(z - z0).max() <= 1e-10 * max(1.0, np.abs(z0).max()), sw
+        assert abs(its - its0) <= 3, (sw, its, its0)
+
+
+def test_upper_triangle_coarse_assembly_is_bitwise_the_full_one(tmp_path):
+    """Inside the Newton loop the coarse levels project and gather only the upper triangle of H = R'H_blk R (the factorization
+    and `symmetric(H)` read nothing else: src/newton.jl:253, csrc/mf_analysis.cpp).  The entries it forms are the same sums in
+    the same order, so the whole solve is bit for bit the one with MGBHIP_FULL_COARSE_H=1 (both triangles, as in round 3)."""
+    z0, its0 = _solve(tmp_path, "upper", {})
+    z1, its1 = _solve(tmp_path, "full", {"MGBHIP_FULL_COARSE_H": "1"})
+    assert np.array_equal(z0, z1) and its0 == its1

@@ -306,3 +306,60 @@ def test_sharded_config4_fem3d_L6_phase1_matches_single_rank():
         assert abs(int(np.asarray(r["its"]).sum()) - b) <= max(3, 0.02 * b)
         assert abs(int(np.asarray(r["feas"]).sum()) - bf) <= max(3, 0.02 * bf)
     assert np.array_equal(res[0]["z"], res[1]["z"])
+
+
+def _callback_worker(rank, world, port, out):
+    """The collective wrappers of user callables (ShardedSolver._wrap_stopping / _wrap_early_stop) without a GPU: a bare
+    ShardedSolver object with just the attributes the wrappers use."""
+    _init(rank, world, port)
+    import types
+    from mgb_amd.sharded import ShardedSolver, _Reducer
+    S = object.__new__(ShardedSolver)
+    S.dist, S.rank, S.world = dist, rank, world
+    S._shard = dict(reduce=_Reducer(dist, "cpu"))
+    S.prob = types.SimpleNamespace(g=np.zeros((6 * world, 2)))          # nu = 2 state components
+    res = {}
+    # stopping rule: rank-dependent answers are MAX-reduced (every rank takes the same branch) ...
+    stop = S._wrap_stopping(lambda *a: rank == 1)
+    res["stop"] = stop(0.0, 0.0, 0.0, np.array([1.0]), None, 0.0, 0.0)
+    # ... and an exception on ONE rank is raised on ALL ranks
+    def bad(*a):
+        if rank == 1:
+            raise ValueError("boom on rank 1")
+        return False
+    try:
+        S._wrap_stopping(bad)(0.0, 0.0, 0.0, np.array([1.0]), None, 0.0, 0.0)
+        res["raised"] = None
+    except Exception as e:                                               # noqa: BLE001
+        res["raised"] = type(e).__name__
+    # early_stop sees the WHOLE stacked iterate [u; s] in global node order, on every rank
+    n_loc = 6
+    u = np.arange(rank * n_loc, (rank + 1) * n_loc, dtype=float)
+    z_loc = np.concatenate([u, 100.0 + u])
+    seen = {}
+    def early(z):
+        seen["z"] = z.copy()
+        return bool(z[: n_loc * world].max() > 10.0) and rank == 0       # only rank 0 says yes: MAX-reduced
+    res["early"] = S._wrap_early_stop(early)(z_loc)
+    res["z"] = seen["z"]
+    res["two"] = S._wrap_early_stop(lambda z, t: t > 1.0)(z_loc, 2.0)
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_user_callables_are_collective_on_a_sharded_problem():
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_callback_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = dict(out)
+    full = np.concatenate([np.arange(12.0), 100.0 + np.arange(12.0)])
+    for rank in range(world):
+        r = res[rank]
+        assert r["stop"] is True                                         # one rank said "stop": all stop
+        assert r["raised"] in ("ValueError", "RuntimeError")             # the raising rank its own error, the peer a RuntimeError
+        assert r["early"] is True and r["two"] is True
+        assert np.array_equal(r["z"], full)
+    assert res[1]["raised"] == "ValueError" and res[0]["raised"] == "RuntimeError"
