@@ -959,13 +959,17 @@ __global__ __launch_bounds__(256) void csr_matvec_chunk_kernel(const int32_t* __
     }
 }
 
+// one wave per row: the lanes stride over the chunk sums (a row of the coarsest level has 224 of them at L = 9; one thread
+// walking them serially took 19 us for a 2-row matvec), fixed shuffle tree
 __global__ __launch_bounds__(256) void csr_matvec_chunk_sum_kernel(int64_t rows, const double* __restrict__ partial,
                                                                    int nchunk, double* __restrict__ y) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= rows) return;
     DSum a;
-    for (int c = 0; c < nchunk; ++c) a.merge(partial[2 * (i * nchunk + c)], partial[2 * (i * nchunk + c) + 1]);
-    y[i] = a.value();
+    for (int c = lane; c < nchunk; c += 64) a.merge(partial[2 * (i * nchunk + c)], partial[2 * (i * nchunk + c) + 1]);
+    dsum_wave_reduce(a);
+    if (lane == 0) y[i] = a.value();
 }
 
 // zfull = z0 + R*s  (src/convex.jl:156): one thread per broken row, so the element kernels
@@ -1738,7 +1742,7 @@ void launch_csr_matvec_chunked(int64_t rows, const int32_t* ptr, const int32_t* 
     if (rows == 0) return;
     hipLaunchKernelGGL(csr_matvec_chunk_kernel, dim3((unsigned)nchunk, (unsigned)rows), dim3(256), 0, st, ptr, col, val, x,
                        scratch, nchunk);
-    hipLaunchKernelGGL(csr_matvec_chunk_sum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows, scratch,
+    hipLaunchKernelGGL(csr_matvec_chunk_sum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rows, scratch,
                        nchunk, y);
     MGB_HIP_CHECK(hipGetLastError());
 }
