@@ -967,13 +967,20 @@ void mgbhip_problem::factor(int level, const double* rhs) {
         // H was not materialised (eval_f2 with materialize = false): the values are the slab + shared sums in d_hel
         MGB_REQUIRE(hel_level == level, "the element blocks of this level's Hessian were overwritten: evaluate f2 again");
         MGB_REQUIRE(rhs != nullptr, "a Hessian kept in the slab is factored together with its right-hand side");
+        const bool dbg2 = [] { const char* e = getenv("MGBHIP_DEBUG"); return e && atoi(e) >= 2; }();
         if (!L.solver.has_direct_map()) {
+            const auto t0 = std::chrono::steady_clock::now();
             L.solver.set_direct_map(L.h_vmap.data(), L.nnz, hel_cap + L.nshared, st);
             std::vector<int32_t>().swap(L.h_vmap);        // 4 B per nonzero: not needed again
+            if (dbg2) fprintf(stderr, "[mgbhip] direct value map level %d: %.2f s\n", level,
+                              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         }
         if (!L.condense_tried) {          // from the next f2 on the element kernel writes the leaf fronts itself
+            const auto t0 = std::chrono::steady_clock::now();
             L.condense_tried = true;
             L.condense = try_enable_condensed(level);
+            if (dbg2) fprintf(stderr, "[mgbhip] condensed-leaf set-up level %d: %.2f s\n", level,
+                              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         }
         MGB_REQUIRE(!L.H_condensed || rhs == L.condensed_rhs, "condensed leaves were formed for another right-hand side");
         double* tail = d_hel.p + hel_cap + L.nshared;

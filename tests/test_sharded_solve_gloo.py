@@ -104,7 +104,7 @@ def _cpu_worker(rank, world, port, kind, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world", [("fem2d_P2_L3", 2), ("fem3d_L3", 2), ("fem2d_P2_L3", 3)])
+@pytest.mark.parametrize("kind,world", [("fem2d_P2_L3", 2), ("fem3d_L3", 2), ("fem2d_P2_L3", 3), ("fem2d_P2_L3", 4)])
 def test_domain_decomposition_reproduces_single_rank_newton_direction(kind, world):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -363,3 +363,25 @@ def test_user_callables_are_collective_on_a_sharded_problem():
         assert r["early"] is True and r["two"] is True
         assert np.array_equal(r["z"], full)
     assert res[1]["raised"] == "ValueError" and res[0]["raised"] == "RuntimeError"
+
+
+@pytest.mark.gpu
+def test_sharded_mgb_solve_four_ranks_sharing_the_device():
+    """G = 4 (the largest world the one-GPU box allows: at most six processes on the card): fem2d_P2 L = 5 over four ranks --
+    the interface is the union of three cuts, every rank factors it redundantly -- against the
+    single-rank solve: z to 1e-8, every level solve within +-1 iteration."""
+    import mgb_amd as m
+    world = 4
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_gpu_worker, args=(world, _free_port(), "fem2d_P2_L5", out), nprocs=world, join=True)
+        res = dict(out)
+    ref = m.mgb_solve(_problem("fem2d_P2_L5"))
+    b = np.asarray(ref.SOL_main["its"])
+    for rank in range(world):
+        r = res[rank]
+        a = np.asarray(r["its"])
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1, (a.sum(axis=1), b.sum(axis=1))
+        assert np.abs(r["z"] - ref.z).max() < 1e-8
+    assert all(np.array_equal(res[0]["z"], res[k]["z"]) for k in range(1, world))
