@@ -1,7 +1,7 @@
 """MI355X-native backend for the MultiGridBarrier.jl inner Newton hot path.
 
 Host-side mirror of the reference interface for this path: `fem1d/fem2d/fem3d/
-fem2d_P2/spectral1d/spectral2d`, `subdivide`, `amg`, `assemble`, `mgb_solve` with a
+fem2d_P1/fem2d_P2/spectral1d/spectral2d`, `subdivide`, `amg`, `assemble`, `mgb_solve` with a
 `device=HIPDevice` keyword (reference: src/MultiGridBarrier.jl exports, src/device.jl).
 Setup (meshes, hierarchies, grids) is NumPy on the CPU exactly as in the reference;
 everything from `mgb_solve` down runs in the HIP library `libmgbhip.so` through its
@@ -10,6 +10,7 @@ library raises.
 """
 from .blockmatrices import BlockDiag, BlockColumn
 from .multigrid import Geometry, MultiGrid, AMG, prepare_amg, amg_helper
+from .fem2d_p1 import fem2d_P1, FEM2D_P1
 from .fem2d_p2 import fem2d_P2, FEM2D_P2
 from .tensorfem import fem1d, fem2d, fem3d, TensorFEM, tensor_dofmap
 from .spectral import spectral1d, spectral2d, SPECTRAL1D, SPECTRAL2D

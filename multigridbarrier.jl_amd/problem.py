@@ -11,7 +11,7 @@ from typing import Any, Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import fem2d_p2, spectral, tensorfem
+from . import fem2d_p1, fem2d_p2, spectral, tensorfem
 from .convex import Convex, convex_Euclidian_power
 from .multigrid import AMG, Geometry, MultiGrid, prepare_amg
 
@@ -102,6 +102,8 @@ def assemble(mg: MultiGrid, dim: Optional[int] = None, state_variables=None, D=N
 
 def amg(geom: Geometry, **kw) -> MultiGrid:
     disc = geom.discretization
+    if isinstance(disc, fem2d_p1.FEM2D_P1):
+        return fem2d_p1.amg(geom, **kw)
     if isinstance(disc, fem2d_p2.FEM2D_P2):
         return fem2d_p2.amg(geom, **kw)
     if isinstance(disc, tensorfem.TensorFEM):
@@ -113,6 +115,8 @@ def amg(geom: Geometry, **kw) -> MultiGrid:
 
 def subdivide(geom: Geometry, L: int) -> Geometry:
     disc = geom.discretization
+    if isinstance(disc, fem2d_p1.FEM2D_P1):
+        return fem2d_p1.subdivide(geom, L)
     if isinstance(disc, fem2d_p2.FEM2D_P2):
         return fem2d_p2.subdivide(geom, L)
     if isinstance(disc, tensorfem.TensorFEM):
@@ -125,6 +129,8 @@ def subdivide(geom: Geometry, L: int) -> Geometry:
 def geometric_mg(geom: Geometry, L: int) -> MultiGrid:
     """reference: `geometric_mg`, src/multigrid.jl:422-431 (spectral discretizations ignore L and return `amg`)."""
     disc = geom.discretization
+    if isinstance(disc, fem2d_p1.FEM2D_P1):
+        return fem2d_p1.geometric_mg(geom, L)
     if isinstance(disc, fem2d_p2.FEM2D_P2):
         return fem2d_p2.geometric_mg(geom, L)
     if isinstance(disc, tensorfem.TensorFEM):
@@ -136,6 +142,8 @@ def geometric_mg(geom: Geometry, L: int) -> MultiGrid:
 
 def find_boundary(geom: Geometry):
     disc = geom.discretization
+    if isinstance(disc, fem2d_p1.FEM2D_P1):
+        return fem2d_p1.find_boundary(geom)
     if isinstance(disc, fem2d_p2.FEM2D_P2):
         return fem2d_p2.find_boundary(geom)
     if isinstance(disc, tensorfem.TensorFEM):

@@ -9,6 +9,8 @@ def build_case(c):
         geom = m.fem1d(nodes=np.linspace(-1, 1, c["nodes"]))
     elif g == "fem2d_P2":
         geom = m.subdivide(m.fem2d_P2(), c["L"])
+    elif g == "fem2d_P1":
+        geom = m.subdivide(m.fem2d_P1(), c["L"])
     elif g == "fem3d":
         geom = m.subdivide(m.fem3d(k=c["k"]), c["L"])
     elif g == "spectral1d":

@@ -9,7 +9,8 @@ from helpers import build_case, build_geom, gold_z, lower_bound_problem, parabol
 from oracle import mgb_oracle as O
 
 CASES = ["fem1d_3nodes_p1", "fem2d_P2_L1_p1", "spectral1d_n5_p1", "spectral2d_n5_p1", "fem1d_5nodes_p1",
-         "fem1d_5nodes_p1.5", "fem2d_P2_L2_p1", "fem2d_P2_L2_p1.5", "fem3d_k1_L2_p1", "fem3d_k1_L2_p1.5"]
+         "fem1d_5nodes_p1.5", "fem2d_P1_L2_p1", "fem2d_P1_L2_p1.5", "fem2d_P2_L2_p1", "fem2d_P2_L2_p1.5", "fem3d_k1_L2_p1",
+         "fem3d_k1_L2_p1.5"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -31,6 +32,7 @@ def test_oracle_reproduces_reference_parabolic_golden(name):
 
 
 @pytest.mark.parametrize("name,geom", [("fem1d_5nodes_p1", lambda: m.fem1d(nodes=np.linspace(-1, 1, 5))),
+                                       ("fem2d_P1_L2_p1.5", lambda: m.subdivide(m.fem2d_P1(), 2)),
                                        ("fem2d_P2_L2_p1.5", lambda: m.subdivide(m.fem2d_P2(), 2)),
                                        ("fem3d_k1_L2_p1", lambda: m.subdivide(m.fem3d(k=1), 2))])
 def test_goldens_are_prolongator_independent(golden, name, geom):

@@ -240,3 +240,42 @@ def test_default_ladder_sizes_and_their_sensitivity_to_the_unpinned_prefilter(L,
     assert plain[0][0] <= 2 and plain[1][0] <= 2 and quirk[0][0] <= 2 and quirk[1][0] <= 2      # max_coarse = 2 in each subspace
     if L == 9:
         assert plain[0][0] + plain[1][0] == 2 and quirk[0][0] + quirk[1][0] == 2
+
+
+def test_fem2d_P1_operators_weights_and_hierarchy():
+    """fem2d_P1 (reference: src/fem2d_P1.jl): derivative blocks exact on linears, weights = area / 3 per corner, red refinement
+    keeps the child order of the 12 x 3 table, the zero-trace spaces are nested, `amg` and `geometric_mg` agree on the finest
+    :dirichlet space, and `find_boundary` marks every doubled copy of a boundary corner."""
+    g1 = m.fem2d_P1()
+    assert g1.x.shape == (3, 2, 2) and g1.t.shape == (3, 2) and int(g1.t.max()) + 1 == 4
+    geom = m.subdivide(g1, 3)
+    V, N = geom.t.shape
+    assert (V, N) == (3, 32) and np.isclose(geom.w.sum(), 4.0)
+    x = geom.xflat
+    u = 2.0 + 3.0 * x[:, 0] - 0.5 * x[:, 1]
+    assert np.allclose(geom.operators["dx"].matvec(u), 3.0, atol=1e-12)
+    assert np.allclose(geom.operators["dy"].matvec(u), -0.5, atol=1e-12)
+    assert geom.operators["id"].is_identity()
+    # labels: coincident doubled nodes share an id and only they do
+    lab = geom.labels
+    for a in range(0, lab.size, 7):
+        same = np.flatnonzero(lab == lab[a])
+        assert np.allclose(x[same], x[a])
+    bnd = m.find_boundary(geom)
+    on = np.array([v + 3 * e for (v, e) in bnd])
+    assert np.all(np.isclose(np.abs(x[on]).max(axis=1), 1.0))
+    off = np.setdiff1d(np.arange(3 * N), on)
+    assert np.all(np.abs(x[off]).max(axis=1) < 1.0 - 1e-12)
+    mg_a, mg_g = m.amg(geom), m.geometric_mg(g1, 3)
+    assert np.array_equal(mg_g.geometry.t, geom.t) and np.allclose(mg_g.geometry.x, geom.x)
+    Ra, Rg = sp.csr_matrix(mg_a.R["dirichlet"][-1]), sp.csr_matrix(mg_g.R["dirichlet"][-1])
+    assert Ra.shape == Rg.shape == (3 * N, 9) and abs(Ra - Rg).max() == 0          # 9 interior corners of the 4 x 4 grid
+    for R in mg_a.R["dirichlet"]:                                                  # coarse spaces inside the fine zero-trace space
+        R = sp.csr_matrix(R)
+        coef = Ra.T @ R
+        cnt = np.asarray(Ra.sum(axis=0)).ravel()
+        assert abs(Ra @ sp.diags(1.0 / cnt) @ coef - R).max() < 1e-12
+    for R in mg_a.R["uniform"]:
+        assert np.allclose(np.asarray(sp.csr_matrix(R).todense()), 1.0, atol=1e-13)
+    prob = m.assemble(mg_a, p=1.5)
+    assert prob.M[0].D_fine[0].active_block.p == 3 and len(prob.M[0].D_fine) == 4
