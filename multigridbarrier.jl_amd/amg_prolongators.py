@@ -25,6 +25,8 @@ from typing import Callable, List
 import numpy as np
 import scipy.sparse as sp
 
+from . import _setup_native
+
 
 def _classical_strength(A: sp.csr_matrix, theta: float) -> sp.csr_matrix:
     """S[i, j] != 0 iff j strongly influences i: |a_ij| >= theta * max_{k != i} |a_ik|."""
@@ -68,6 +70,14 @@ def _rs_cf_splitting(S: sp.csr_matrix, diag_quirk: bool = False) -> np.ndarray:
     S.sort_indices()
     ST = sp.csr_matrix(S.T)
     ST.sort_indices()
+    if _setup_native.available() and S.nnz < 2**31 - 1:   # the same loop in C++ (csrc/setup_host.cpp); tests compare the two
+        return _setup_native.rs_cf_splitting(S.indptr, S.indices, ST.indptr, ST.indices, diag_quirk)
+    return _rs_cf_splitting_loop(S, ST, diag_quirk)
+
+
+def _rs_cf_splitting_loop(S: sp.csr_matrix, ST: sp.csr_matrix, diag_quirk: bool) -> np.ndarray:
+    """The splitting loop itself in Python (S, S' with sorted rows): the readable statement and the test twin of the C++ loop."""
+    n = S.shape[0]
     Sp, Sj = S.indptr.tolist(), S.indices.tolist()        # S row i: the nodes i depends on
     Tp, Tj = ST.indptr.tolist(), ST.indices.tolist()      # T row i: the nodes that depend on i
     lam = [Tp[i + 1] - Tp[i] for i in range(n)]

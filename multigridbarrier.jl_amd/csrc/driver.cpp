@@ -381,6 +381,7 @@ int core_run(mgbhip_problem* P, double* z, const double* c, const mgbhip_options
     const size_t zn = (size_t)P->nu * P->n;
     const size_t cn = (size_t)P->n * P->nD;
     const int L = (int)P->levels.size();
+    P->prepare_all();
     P->d_z.upload(z, zn, st);
     P->d_c0.upload(c, cn, st);
     P->cnt = Counters();

@@ -99,6 +99,9 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     MGB_REQUIRE(d->n_ops >= 1 && d->n_ops <= MGBHIP_MAX_OPS, "operator count out of range");
     MGB_REQUIRE(d->L >= 1 && d->R && d->w, "missing hierarchy or weights");
     MGB_HIP_CHECK(hipSetDevice(ctx->device));
+    const auto t_create0 = std::chrono::steady_clock::now();
+    const bool dbg2 = [] { const char* e = getenv("MGBHIP_DEBUG"); return e && atoi(e) >= 2; }();
+    auto since0 = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create0).count(); };
     std::unique_ptr<mgbhip_problem> P(new mgbhip_problem());
     P->ctx = ctx;
     P->p = d->p;
@@ -209,6 +212,7 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
         P->bw.upload(d->barrier_weights, (size_t)P->n, st);
         P->has_bw = true;
     }
+    if (dbg2) fprintf(stderr, "[mgbhip] problem_create: operators, weights and cone grids on the device after %.3f s\n", since0());
     // hierarchy
     P->levels.resize(d->L);
     for (int l = 0; l < d->L; ++l) MGB_REQUIRE(d->R[l].rows == (int64_t)P->nu * P->n, "prolongation row count must be nu*n");
@@ -220,7 +224,10 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
             (void)hipSetDevice(ctx->device);
             for (int l = next.fetch_add(1); l < d->L; l = next.fetch_add(1)) {
                 try {
+                    const double t0 = since0();
                     upload_csr(d->R[l], P->levels[l], st);
+                    if (dbg2) fprintf(stderr, "[mgbhip] problem_create: level %d (nnz %lld) %.3f -> %.3f s\n", l,
+                                      (long long)d->R[l].rowptr[d->R[l].rows], t0, since0());
                 } catch (...) {
                     errors[(size_t)l] = std::current_exception();
                 }
@@ -234,6 +241,7 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
         for (const auto& e : errors)
             if (e) std::rethrow_exception(e);
     }
+    if (dbg2) fprintf(stderr, "[mgbhip] problem_create: %d levels uploaded after %.3f s\n", d->L, since0());
     // workspace
     int64_t mmax = 1;
     for (auto& L : P->levels) mmax = std::max(mmax, L.m);
@@ -265,6 +273,7 @@ mgbhip_problem* problem_create(mgbhip_ctx* ctx, const mgbhip_problem_desc* d, mg
     }
     P->d_flag.alloc(4);
     MGB_HIP_CHECK(hipStreamSynchronize(st));
+    if (dbg2) fprintf(stderr, "[mgbhip] problem_create: done after %.3f s\n", since0());
     return P.release();
 }
 
@@ -928,60 +937,109 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
     cnt.f2++;
 }
 
+void mgbhip_problem::ensure_analysis(int level) {
+    Level& L = levels[level];
+    if (L.solver.analyzed) return;
+    hipStream_t st = stream();
+    const auto t0 = std::chrono::steady_clock::now();
+    // ordering hint: the centroid of every level-J basis function, sum_i |R_ij| x_i / sum_i |R_ij|
+    std::vector<double> cen;
+    if (!hx.empty() && xdim > 0 && !L.hRptr.empty()) {
+        cen.assign((size_t)L.m * xdim, 0.0);
+        std::vector<double> wsum((size_t)L.m, 0.0);
+        for (int64_t r = 0; r < L.rows; ++r) {
+            const int64_t node = r % n;
+            for (int32_t q = L.hRptr[r]; q < L.hRptr[r + 1]; ++q) {
+                const double a = std::fabs(L.hRval[q]);
+                const int32_t j = L.hRcol[q];
+                wsum[j] += a;
+                for (int d = 0; d < xdim; ++d) cen[(size_t)j * xdim + d] += a * hx[(size_t)d * n + node];
+            }
+        }
+        for (int64_t j = 0; j < L.m; ++j)
+            for (int d = 0; d < xdim; ++d) cen[(size_t)j * xdim + d] = wsum[j] > 0 ? cen[(size_t)j * xdim + d] / wsum[j] : 0.0;
+    }
+    // candidates for condensed leaves (try_enable_condensed) keep their per-element leaf fronts unmerged
+    const bool leaves = L.selection && L.direct && !dense && nu == 2 && p == 7;
+    if (L.sharded) {
+        mgbhip_problem* self = this;
+        L.solver.iface_reduce = [self](double* d, int64_t cnt2) { self->allreduce_device(d, cnt2, 0); };
+    }
+    L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st, cen.empty() ? nullptr : cen.data(), xdim, leaves,
+                     L.sharded ? L.h_iface.data() : nullptr, L.sharded ? (int64_t)L.h_iface.size() : 0);
+    if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
+        fprintf(stderr, "[mgbhip] symbolic analysis level %d (m=%lld, nnz=%lld): %.2f s\n", level, (long long)L.m,
+                (long long)L.nnz, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+}
+
+// Everything the first Newton iteration of every level would build lazily -- assembly plan, symbolic analysis, direct value map,
+// condensed-leaf descriptors -- built now, the levels side by side on host threads (they are independent; the finest level's
+// analysis is the long pole and starts first).  mgb_core calls this once per problem image: time to first solution.
+void mgbhip_problem::prepare_all() {
+    if (prepared) return;
+    prepared = true;
+    static const bool off = [] { const char* e = getenv("MGBHIP_LAZY_PLANS"); return e && e[0] == '1'; }();
+    if (off || dense || sharded() || levels.size() < 2) return;     // sharded levels order their collectives: stay lazy
+    const int Ln = (int)levels.size();
+    std::vector<std::exception_ptr> errors((size_t)Ln);
+    std::atomic<int> next{Ln - 1};
+    auto worker = [&] {
+        (void)hipSetDevice(ctx->device);
+        for (int l = next.fetch_sub(1); l >= 0; l = next.fetch_sub(1)) {
+            try {
+                Level& L = levels[l];
+                if (L.sharded) continue;
+                ensure_plan(l);
+                if (L.m < 1) continue;
+                ensure_analysis(l);
+                ensure_direct(l);
+            } catch (...) {
+                errors[(size_t)l] = std::current_exception();
+            }
+        }
+    };
+    const int nthreads = std::min(Ln, 6);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    for (const auto& e : errors)
+        if (e) std::rethrow_exception(e);
+}
+
+// Direct value map (the factorization reads the element-block slab, H is never materialised) and the condensed leaves of a
+// selection level: needs the plan and the analysis.
+void mgbhip_problem::ensure_direct(int level) {
+    Level& L = levels[level];
+    if (!(L.selection && L.direct) || dense || !L.solver.analyzed) return;
+    hipStream_t st = stream();
+    const bool dbg2 = [] { const char* e = getenv("MGBHIP_DEBUG"); return e && atoi(e) >= 2; }();
+    if (!L.solver.has_direct_map()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        L.solver.set_direct_map(L.h_vmap.data(), L.nnz, hel_cap + L.nshared, st);
+        std::vector<int32_t>().swap(L.h_vmap);        // 4 B per nonzero: not needed again
+        if (dbg2) fprintf(stderr, "[mgbhip] direct value map level %d: %.2f s\n", level,
+                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    if (!L.condense_tried) {          // from the next f2 on the element kernel writes the leaf fronts itself
+        const auto t0 = std::chrono::steady_clock::now();
+        L.condense_tried = true;
+        L.condense = try_enable_condensed(level);
+        if (dbg2) fprintf(stderr, "[mgbhip] condensed-leaf set-up level %d: %.2f s\n", level,
+                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+}
+
 void mgbhip_problem::factor(int level, const double* rhs) {
     Level& L = levels[level];
     MGB_REQUIRE(L.have_H, "solve requested before any Hessian was assembled at this level");
     hipStream_t st = stream();
-    if (!L.solver.analyzed) {
-        const auto t0 = std::chrono::steady_clock::now();
-        // ordering hint: the centroid of every level-J basis function, sum_i |R_ij| x_i / sum_i |R_ij|
-        std::vector<double> cen;
-        if (!hx.empty() && xdim > 0 && !L.hRptr.empty()) {
-            cen.assign((size_t)L.m * xdim, 0.0);
-            std::vector<double> wsum((size_t)L.m, 0.0);
-            for (int64_t r = 0; r < L.rows; ++r) {
-                const int64_t node = r % n;
-                for (int32_t q = L.hRptr[r]; q < L.hRptr[r + 1]; ++q) {
-                    const double a = std::fabs(L.hRval[q]);
-                    const int32_t j = L.hRcol[q];
-                    wsum[j] += a;
-                    for (int d = 0; d < xdim; ++d) cen[(size_t)j * xdim + d] += a * hx[(size_t)d * n + node];
-                }
-            }
-            for (int64_t j = 0; j < L.m; ++j)
-                for (int d = 0; d < xdim; ++d) cen[(size_t)j * xdim + d] = wsum[j] > 0 ? cen[(size_t)j * xdim + d] / wsum[j] : 0.0;
-        }
-        // candidates for condensed leaves (try_enable_condensed) keep their per-element leaf fronts unmerged
-        const bool leaves = L.selection && L.direct && !dense && nu == 2 && p == 7;
-        if (L.sharded) {
-            mgbhip_problem* self = this;
-            L.solver.iface_reduce = [self](double* d, int64_t cnt2) { self->allreduce_device(d, cnt2, 0); };
-        }
-        L.solver.analyze(L.m, L.hHptr.data(), L.hHcol.data(), st, cen.empty() ? nullptr : cen.data(), xdim, leaves,
-                         L.sharded ? L.h_iface.data() : nullptr, L.sharded ? (int64_t)L.h_iface.size() : 0);
-        if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
-            fprintf(stderr, "[mgbhip] symbolic analysis level %d (m=%lld, nnz=%lld): %.2f s\n", level, (long long)L.m,
-                    (long long)L.nnz, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    }
+    ensure_analysis(level);
     if (L.H_in_slab) {
         // H was not materialised (eval_f2 with materialize = false): the values are the slab + shared sums in d_hel
         MGB_REQUIRE(hel_level == level, "the element blocks of this level's Hessian were overwritten: evaluate f2 again");
         MGB_REQUIRE(rhs != nullptr, "a Hessian kept in the slab is factored together with its right-hand side");
-        const bool dbg2 = [] { const char* e = getenv("MGBHIP_DEBUG"); return e && atoi(e) >= 2; }();
-        if (!L.solver.has_direct_map()) {
-            const auto t0 = std::chrono::steady_clock::now();
-            L.solver.set_direct_map(L.h_vmap.data(), L.nnz, hel_cap + L.nshared, st);
-            std::vector<int32_t>().swap(L.h_vmap);        // 4 B per nonzero: not needed again
-            if (dbg2) fprintf(stderr, "[mgbhip] direct value map level %d: %.2f s\n", level,
-                              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-        }
-        if (!L.condense_tried) {          // from the next f2 on the element kernel writes the leaf fronts itself
-            const auto t0 = std::chrono::steady_clock::now();
-            L.condense_tried = true;
-            L.condense = try_enable_condensed(level);
-            if (dbg2) fprintf(stderr, "[mgbhip] condensed-leaf set-up level %d: %.2f s\n", level,
-                              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-        }
+        ensure_direct(level);
         MGB_REQUIRE(!L.H_condensed || rhs == L.condensed_rhs, "condensed leaves were formed for another right-hand side");
         double* tail = d_hel.p + hel_cap + L.nshared;
         launch_border_tail(rhs, tail, L.m, st);

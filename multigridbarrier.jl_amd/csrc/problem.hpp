@@ -139,6 +139,10 @@ struct mgbhip_problem {
     mgbhip::ElemParams base_params(int level, const double* d_s, const double* d_zz, const double* d_cc) const;
     hipStream_t stream() const { return ctx->stream; }
     void ensure_plan(int level);
+    void ensure_analysis(int level);
+    void ensure_direct(int level);
+    void prepare_all();
+    bool prepared = false;
     void ensure_plan_dense(int level);
     double eval_f0(int level, const double* d_s, const double* d_zz, const double* d_cc);
     // kernels only: the value lands in d_scal[0]; the caller batches the read-back

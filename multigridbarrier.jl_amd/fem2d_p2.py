@@ -136,37 +136,36 @@ def reference_triangle(bubble: bool = True) -> dict:
 _CHILD_CORNERS = ((5, 0, 1), (1, 2, 3), (3, 4, 5), (1, 3, 5))
 
 
+def _first_occurrence_rank(keys: np.ndarray) -> Tuple[np.ndarray, int]:
+    """0-based id of every key, ids handed out in order of first occurrence; also the number of distinct keys."""
+    _, first, inv = np.unique(keys, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    return rank[inv], int(order.size)
+
+
 def _refine_p2_connectivity(t: np.ndarray) -> np.ndarray:
     """Red-refine full P2(+bubble) connectivity (reference: src/fem2d_P2.jl:169-207).
     Node ids are renumbered by first occurrence, child-edge nodes keyed by their
-    (sorted) endpoint pair, bubbles element-local."""
+    (sorted) endpoint pair, bubbles element-local: the reference hands out the new ids child by child -- the
+    three edge nodes a child meets first, then its bubble -- which is the first-occurrence rank of the event
+    sequence (edge, edge, edge, bubble) per child."""
     V, N = t.shape
+    ids, n0 = _first_occurrence_rank(np.ascontiguousarray(t[:6].T).reshape(-1))
+    ids = ids.reshape(N, 6)
+    corners = ids[:, np.array(_CHILD_CORNERS)].reshape(4 * N, 3)       # child j = 4 e + s
+    nxt = corners[:, [1, 2, 0]]
+    events = np.minimum(corners, nxt).astype(np.int64) * n0 + np.maximum(corners, nxt)
+    if V == 7:
+        events = np.concatenate([events, (np.int64(n0) * n0 + np.arange(4 * N, dtype=np.int64))[:, None]], axis=1)
+    new_ids, _ = _first_occurrence_rank(events.reshape(-1))
+    new_ids = n0 + new_ids.reshape(4 * N, -1)
     out = np.empty((V, 4 * N), dtype=np.int64)
-    node_ids: Dict[int, int] = {}
-    for e in range(N):
-        for v in range(6):
-            i = int(t[v, e])
-            if i not in node_ids:
-                node_ids[i] = len(node_ids)
-    edge_nodes: Dict[Tuple[int, int], int] = {}
-    next_id = len(node_ids)
-    for e in range(N):
-        ids = [node_ids[int(t[v, e])] for v in range(6)]
-        for s, cc in enumerate(_CHILD_CORNERS):
-            j = 4 * e + s
-            corners = (ids[cc[0]], ids[cc[1]], ids[cc[2]])
-            out[0, j], out[2, j], out[4, j] = corners
-            for slot, u, v in ((1, corners[0], corners[1]), (3, corners[1], corners[2]), (5, corners[2], corners[0])):
-                key = (u, v) if u < v else (v, u)
-                eid = edge_nodes.get(key)
-                if eid is None:
-                    eid = next_id
-                    next_id += 1
-                    edge_nodes[key] = eid
-                out[slot, j] = eid
-            if V == 7:
-                out[6, j] = next_id
-                next_id += 1
+    out[0], out[2], out[4] = corners[:, 0], corners[:, 1], corners[:, 2]
+    out[1], out[3], out[5] = new_ids[:, 0], new_ids[:, 1], new_ids[:, 2]
+    if V == 7:
+        out[6] = new_ids[:, 3]
     return out
 
 

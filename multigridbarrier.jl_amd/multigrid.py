@@ -13,11 +13,13 @@ Indices are 0-based throughout (the reference is 1-based Julia); connectivity
 from __future__ import annotations
 
 from dataclasses import dataclass, field
+from collections.abc import Sequence as _SequenceABC
 from typing import Any, Callable, Dict, List, Sequence, Tuple
 
 import numpy as np
 import scipy.sparse as sp
 
+from . import _setup_native
 from .blockmatrices import BlockDiag, block_column
 
 
@@ -163,6 +165,31 @@ def _is_identity(M) -> bool:
     return bool(np.array_equal(M.indices, np.arange(n)) and np.array_equal(M.indptr, np.arange(n + 1)) and np.all(M.data == 1.0))
 
 
+def _matmat(A, B):
+    """`A @ B` for float64 CSR operands through SciPy's own numeric kernel (`csr_matmat`: same entries, same order, same
+    bits as `A @ B`), with the output sized by an upper bound -- the candidates per row -- instead of SciPy's exact counting
+    pass, which costs half as much as the product itself on the composed prolongators (3-4 entries per row)."""
+    try:
+        from scipy.sparse import _sparsetools
+    except ImportError:                                   # private module moved: the plain product is the same matrix
+        return A @ B
+    if not (sp.issparse(A) and sp.issparse(B)) or A.shape[1] != B.shape[0]:
+        return A @ B
+    A, B = sp.csr_matrix(A), sp.csr_matrix(B)
+    if A.dtype != np.float64 or B.dtype != np.float64 or A.nnz == 0 or B.nnz == 0:
+        return A @ B
+    ub = int(np.diff(B.indptr).astype(np.int64)[A.indices].sum())
+    if ub == 0 or max(ub, A.shape[0] + 1, B.shape[1]) >= 2**31 - 1:
+        return A @ B
+    it = np.int32
+    M, N = A.shape[0], B.shape[1]
+    indptr, indices, data = np.empty(M + 1, dtype=it), np.empty(ub, dtype=it), np.empty(ub, dtype=np.float64)
+    _sparsetools.csr_matmat(M, N, np.asarray(A.indptr, dtype=it), np.asarray(A.indices, dtype=it), A.data,
+                            np.asarray(B.indptr, dtype=it), np.asarray(B.indices, dtype=it), B.data, indptr, indices, data)
+    nnz = int(indptr[M])
+    return sp.csr_matrix((data[:nnz].copy(), indices[:nnz].copy(), indptr), shape=(M, N))
+
+
 def _compose_R(subspaces: Dict[str, List[Any]], refine: Dict[str, List[Any]]):
     """reference: src/multigrid.jl:192-204.  The cumulative products level->fine are shared between the
     symbols that ride the same refine ladder (`full`, `uniform` and the riders do), identity subspaces are
@@ -177,7 +204,7 @@ def _compose_R(subspaces: Dict[str, List[Any]], refine: Dict[str, List[Any]]):
             rfp = [None] * L
             rfp[L - 1] = rX[L - 1]
             for l in range(L - 2, -1, -1):
-                rfp[l] = rX[l] if _is_identity(rfp[l + 1]) else rfp[l + 1] @ rX[l]
+                rfp[l] = rX[l] if _is_identity(rfp[l + 1]) else _matmat(rfp[l + 1], rX[l])
             ladders[id(rX)] = rfp
         ops = []
         for l in range(L):
@@ -189,7 +216,7 @@ def _compose_R(subspaces: Dict[str, List[Any]], refine: Dict[str, List[Any]]):
             elif sp.issparse(S) and S.shape[1] == 1 and S.nnz == S.shape[0] and np.all(S.data == 1.0) and sp.issparse(rfp[l]):
                 ops.append(_as_op(sp.csr_matrix(np.asarray(rfp[l].sum(axis=1)).reshape(-1, 1))))
             else:
-                ops.append(_as_op(rfp[l] @ S))
+                ops.append(_as_op(_matmat(rfp[l], S)))
         out[X] = ops
     return out
 
@@ -197,6 +224,8 @@ def _compose_R(subspaces: Dict[str, List[Any]], refine: Dict[str, List[Any]]):
 def _as_op(M):
     if sp.issparse(M):
         M = sp.csr_matrix(M)
+        if not M.has_sorted_indices:
+            _setup_native.csr_sort_rows(M)       # short rows: an in-place insertion sort (csrc/setup_host.cpp); same result
         M.sum_duplicates()
         M.sort_indices()
         return M
@@ -325,6 +354,30 @@ def _blockdiag(mats):
     return out
 
 
+class LazyLevels(_SequenceABC):
+    """A read-only list whose entries are built on first access (`make(l)`) and kept."""
+
+    def __init__(self, n: int, make: Callable[[int], Any]):
+        self._make = make
+        self._items: List[Any] = [None] * n
+        self._built = [False] * n
+
+    def __len__(self) -> int:
+        return len(self._items)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self._items)))]
+        n = len(self._items)
+        j = i + n if i < 0 else i
+        if not 0 <= j < n:
+            raise IndexError("level index out of range")
+        if not self._built[j]:
+            self._items[j] = self._make(j)
+            self._built[j] = True
+        return self._items[j]
+
+
 def amg_helper(mg: MultiGrid, state_variables, D) -> AMG:
     """reference: src/multigrid.jl:474-512.  `state_variables` is a list of
     (name, subspace) rows, `D` a list of (state name, operator name) rows."""
@@ -340,7 +393,11 @@ def amg_helper(mg: MultiGrid, state_variables, D) -> AMG:
     L = len(mg.R[state_variables[0][1]])
     if w.shape != (x.shape[0],):
         raise ValueError(f"quadrature weights have length {w.size} but the mesh has {x.shape[0]} nodes")
-    R_fine = [_blockdiag([mg.R[sv[1]][l] for sv in state_variables]) for l in range(L)]
+    for sv in state_variables:
+        mg.R[sv[1]]                          # an unknown subspace is an error here, not at first use
+    # block-diagonal prolongators, one per level, built when first read: the phase-I pair member (three state variables) is
+    # only read when a start is infeasible, and its eleven concatenations at L = 9 were a third of `assemble`
+    R_fine = LazyLevels(L, lambda l: _blockdiag([mg.R[sv[1]][l] for sv in state_variables]))
     bar = {sv[0]: k for k, sv in enumerate(state_variables)}
     D_fine, D_spec = [], []
     for k, (var, opname) in enumerate(D):

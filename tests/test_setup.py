@@ -279,3 +279,73 @@ def test_fem2d_P1_operators_weights_and_hierarchy():
         assert np.allclose(np.asarray(sp.csr_matrix(R).todense()), 1.0, atol=1e-13)
     prob = m.assemble(mg_a, p=1.5)
     assert prob.M[0].D_fine[0].active_block.p == 3 and len(prob.M[0].D_fine) == 4
+
+
+def test_native_setup_helpers_are_bitwise_their_python_twins():
+    """csrc/setup_host.cpp (libmgbsetup.so) restates two sequential loops of the hierarchy construction in C++: the
+    Ruge-Stueben splitting and the per-row index sort.  Both must give exactly what the Python / SciPy twins give --
+    C/F splittings on mesh Laplacians and on random strength graphs (with and without the pre-filter), sorted products,
+    and the whole ladder of a P2 mesh."""
+    from mgb_amd import _setup_native as nat, amg_prolongators as ap
+    if not nat.available():
+        pytest.skip("libmgbsetup.so not built")
+    rng = np.random.default_rng(5)
+    mats = [sp.csr_matrix(m.amg(m.subdivide(m.fem2d_P2(), 3)).R["full"][-2].T @ m.amg(m.subdivide(m.fem2d_P2(), 3)).R["full"][-2])]
+    for n, dens in ((1, 1.0), (2, 1.0), (40, 0.1), (300, 0.02), (300, 0.3)):
+        A = sp.random(n, n, density=dens, random_state=int(rng.integers(1 << 30)), format="csr")
+        mats.append(sp.csr_matrix(A + A.T + sp.identity(n)))
+    for A in mats:
+        S = ap._classical_strength(-abs(A) + 2 * sp.diags(np.asarray(abs(A).sum(axis=1)).ravel()), 0.25)
+        S.sort_indices()
+        ST = sp.csr_matrix(S.T)
+        ST.sort_indices()
+        for quirk in (False, True):
+            want = ap._rs_cf_splitting_loop(S, ST, quirk)
+            got = nat.rs_cf_splitting(S.indptr, S.indices, ST.indptr, ST.indices, quirk)
+            assert np.array_equal(want, got)
+            assert np.array_equal(ap._rs_cf_splitting(S, quirk), want)
+    # row sort: the unsorted output of a sparse product against scipy's own sort
+    A = sp.random(500, 80, density=0.05, random_state=3, format="csr")
+    B = sp.random(80, 90, density=0.2, random_state=4, format="csr")
+    C1 = A @ B
+    C2 = C1.copy()
+    assert not C1.has_sorted_indices
+    assert nat.csr_sort_rows(C1)
+    C2.sort_indices()
+    assert np.array_equal(C1.indices, C2.indices) and np.array_equal(C1.data, C2.data) and np.array_equal(C1.indptr, C2.indptr)
+    wide = sp.csr_matrix(np.arange(1.0, 41.0)[None, ::-1])          # one row of 40 entries: the std::stable_sort branch
+    wide.indices[:] = wide.indices[::-1].copy()
+    wide.has_sorted_indices = False
+    w2 = wide.copy(); w2.has_sorted_indices = False; w2.sort_indices()
+    assert nat.csr_sort_rows(wide) and np.array_equal(wide.indices, w2.indices) and np.array_equal(wide.data, w2.data)
+    # the whole ladder, native helpers against the Python twins (fresh interpreter state is not needed: the switch is read per call)
+    g = m.subdivide(m.fem2d_P2(), 4)
+    mg_nat = m.amg(g)
+    nat._LIB, nat._TRIED = None, True                                # force the twins
+    try:
+        mg_py = m.amg(g)
+    finally:
+        nat._TRIED = False
+    for sym in mg_nat.R:
+        for a, b in zip(mg_nat.R[sym], mg_py.R[sym]):
+            a, b = sp.csr_matrix(a), sp.csr_matrix(b)
+            assert a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+            assert np.array_equal(a.data, b.data)
+
+
+def test_upper_bound_product_is_bitwise_scipys():
+    """`multigrid._matmat` skips SciPy's counting pass; the product must be SciPy's, entry for entry and in SciPy's (unsorted)
+    storage order -- the next product of the ladder sums in that order.  Includes exact cancellations (dropped by the kernel)."""
+    from mgb_amd.multigrid import _matmat
+    for seed, (a, b, c, da, db) in enumerate([(400, 60, 70, 0.05, 0.2), (50, 50, 5, 0.3, 0.5), (7, 3, 1, 1.0, 1.0)]):
+        A = sp.random(a, b, density=da, random_state=seed, format="csr")
+        B = sp.random(b, c, density=db, random_state=seed + 10, format="csr")
+        want, got = A @ B, _matmat(A, B)
+        n = int(want.indptr[-1])
+        assert got.shape == want.shape and np.array_equal(got.indptr, want.indptr)
+        assert np.array_equal(got.indices, want.indices[:n]) and np.array_equal(got.data, want.data[:n])
+    A = sp.csr_matrix(np.array([[1.0, 1.0], [2.0, 0.0]]))
+    B = sp.csr_matrix(np.array([[1.0, 3.0], [-1.0, 4.0]]))
+    got = _matmat(A, B)
+    assert got.nnz == 3 and np.array_equal(got.toarray(), np.array([[0.0, 7.0], [2.0, 6.0]]))
+    assert abs(_matmat(sp.identity(4, format="csr"), sp.csr_matrix((4, 3))) - sp.csr_matrix((4, 3))).nnz == 0

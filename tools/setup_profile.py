@@ -35,6 +35,8 @@ def main():
     from mgb_amd.device import DeviceMGBProblem
     from mgb_amd.solve import mgb_driver
     os.environ["MGBHIP_DEBUG"] = "2"
+    import torch.cuda
+    torch.cuda.init()                      # context creation is not part of the upload
     t = time.perf_counter(); D = DeviceMGBProblem(prob, device_id=0); print(f"== upload: {time.perf_counter() - t:.3f} s", flush=True)
     t = time.perf_counter(); mgb_driver(D); print(f"== first solve: {time.perf_counter() - t:.3f} s", flush=True)
     os.environ.pop("MGBHIP_DEBUG")
