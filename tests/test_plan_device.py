@@ -58,3 +58,17 @@ def test_condensed_leaves_solve_equals_assembled_solve():
         a, b = np.array(cond[f"z/{name}"]), np.array(plain[f"z/{name}"])
         assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), name
     assert cond["solve/fem1d_L5_p1"][0] == plain["solve/fem1d_L5_p1"][0]              # fem1d has no condensed leaves: bitwise
+
+
+@pytest.mark.gpu
+def test_plans_prepared_side_by_side_equal_the_lazily_built_ones_bitwise():
+    """Round 4 (time to first solution): `mgb_core` builds every level's plan and symbolic analysis on host threads before
+    the first Newton iteration; MGBHIP_LAZY_PLANS=1 keeps the level-by-level order of rounds 1-3.  Same plans, same
+    factorization order: complete solves agree bit for bit (leaf condensation off in both runs -- lazily it would start at the
+    second factorization, prepared at the first, and its summation order differs from the assembled path)."""
+    eager = _run({"MGBHIP_NO_CONDENSE": "1"}, "solve")
+    lazy = _run({"MGBHIP_NO_CONDENSE": "1", "MGBHIP_LAZY_PLANS": "1"}, "solve")
+    keys = [k for k in eager if k.startswith("solve/") or k.startswith("z/")]
+    assert len(keys) >= 4
+    for k in keys:
+        assert eager[k] == lazy[k], k
