@@ -1,8 +1,10 @@
 // setup_host.cpp -- libmgbsetup.so: host-side helpers of the Python setup layer (row f4, time to first solution).
-// Plain C++ (g++, no HIP): the two sequential loops of the AMG hierarchy construction that NumPy cannot vectorise.
+// Plain C++ (g++, no HIP): the sequential loops of the AMG hierarchy construction that NumPy cannot vectorise (Ruge-Stueben
+// splitting, row sorts) and the ladder composition as a chain of sparse products that runs without the interpreter lock.
 // Each has a pure-Python twin in the package that tests/test_setup.py compares bit for bit; the package falls back to
 // the twin when this library has not been built (the setup layer is host code either way -- the Newton path has no fallback).
 #include <algorithm>
+#include <climits>
 #include <cstdint>
 #include <utility>
 #include <vector>
@@ -105,6 +107,84 @@ int mgbsetup_csr_sort_rows(int64_t nrows, const int32_t* ptr, int32_t* idx, doub
         }
     }
     return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ladder composition (reference: src/multigrid.jl:192-204, `refine_fine_prod[l] = refine_fine_prod[l+1] * refine[l]`).
+// A chain handle holds the running product C (CSR, rows in the storage order scipy's `csr_matmat` produces: the reverse
+// of the order in which a row's columns are first touched -- the NEXT product sums in that order, so it is part of the
+// result) and multiplies it by one factor per step with exactly scipy's kernel: same loop, same accumulator array, same
+// dropped exact zeros, no fused multiply-add (built with -ffp-contract=off).  `emit_sorted` writes the current product with
+// sorted rows into caller-owned arrays (what `_as_op` hands to the problem).  One chain per ladder, so the ladders of a
+// hierarchy (full / dirichlet) run on two Python threads: ctypes releases the GIL, scipy's sparsetools do not.
+namespace {
+struct Chain {
+    int64_t rows = 0, cols = 0;
+    std::vector<int32_t> ptr, idx;
+    std::vector<double> val;
+};
+}  // namespace
+
+void* mgbsetup_chain_create(int64_t rows, int64_t cols, const int32_t* ptr, const int32_t* idx, const double* val) {
+    if (rows < 0 || cols < 0 || !ptr) return nullptr;
+    Chain* c = new Chain();
+    c->rows = rows; c->cols = cols;
+    c->ptr.assign(ptr, ptr + rows + 1);
+    const int64_t nnz = ptr[rows];
+    if (nnz > 0) { c->idx.assign(idx, idx + nnz); c->val.assign(val, val + nnz); }
+    return c;
+}
+
+void mgbsetup_chain_destroy(void* h) { delete static_cast<Chain*>(h); }
+
+// C <- C * B (B: brows x bcols CSR, brows == cols of C).  Returns the number of stored entries of the product, -1 on a shape
+// mismatch, -2 if the product exceeds 32-bit indexing.
+int64_t mgbsetup_chain_multiply(void* h, int64_t brows, int64_t bcols, const int32_t* Bp, const int32_t* Bj, const double* Bx) {
+    Chain* c = static_cast<Chain*>(h);
+    if (!c || brows != c->cols || bcols < 0 || !Bp) return -1;
+    std::vector<int32_t> next((size_t)bcols, -1), np((size_t)c->rows + 1, 0), nj;
+    std::vector<double> sums((size_t)bcols, 0.0), nx;
+    nj.reserve(c->idx.size() + c->idx.size() / 4);
+    nx.reserve(c->idx.size() + c->idx.size() / 4);
+    for (int64_t i = 0; i < c->rows; ++i) {
+        int32_t head = -2, length = 0;
+        for (int32_t jj = c->ptr[i]; jj < c->ptr[i + 1]; ++jj) {
+            const int32_t j = c->idx[jj];
+            const double v = c->val[jj];
+            for (int32_t kk = Bp[j]; kk < Bp[j + 1]; ++kk) {
+                const int32_t k = Bj[kk];
+                sums[k] += v * Bx[kk];
+                if (next[k] == -1) { next[k] = head; head = k; ++length; }
+            }
+        }
+        for (int32_t t = 0; t < length; ++t) {
+            if (sums[head] != 0) { nj.push_back(head); nx.push_back(sums[head]); }
+            const int32_t tmp = head;
+            head = next[head];
+            next[tmp] = -1;
+            sums[tmp] = 0;
+        }
+        if (nj.size() >= (size_t)INT32_MAX) return -2;
+        np[(size_t)i + 1] = (int32_t)nj.size();
+    }
+    c->ptr.swap(np); c->idx.swap(nj); c->val.swap(nx);
+    c->cols = bcols;
+    return (int64_t)c->idx.size();
+}
+
+int64_t mgbsetup_chain_nnz(void* h) { return h ? (int64_t)static_cast<Chain*>(h)->idx.size() : -1; }
+
+// The current product with sorted rows into ptr[rows + 1], idx[nnz], val[nnz] (caller-owned).
+int mgbsetup_chain_emit_sorted(void* h, int32_t* ptr, int32_t* idx, double* val) {
+    Chain* c = static_cast<Chain*>(h);
+    if (!c || !ptr) return 1;
+    std::copy(c->ptr.begin(), c->ptr.end(), ptr);
+    if (!c->idx.empty()) {
+        std::copy(c->idx.begin(), c->idx.end(), idx);
+        std::copy(c->val.begin(), c->val.end(), val);
+    }
+    return mgbsetup_csr_sort_rows(c->rows, ptr, idx, val);
 }
 
 }  // extern "C"

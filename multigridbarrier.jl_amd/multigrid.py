@@ -190,22 +190,50 @@ def _matmat(A, B):
     return sp.csr_matrix((data[:nnz].copy(), indices[:nnz].copy(), indptr), shape=(M, N))
 
 
+def _ladder(rX: List[Any]) -> List[Any]:
+    """Cumulative products level -> fine of one refine ladder (reference: src/multigrid.jl:192-204): rfp[L-1] = rX[L-1],
+    rfp[l] = rfp[l+1] * rX[l].  With libmgbsetup.so the chain below the leading identity runs in C++ (the same kernel as
+    scipy's product, on the previous product in scipy's storage order: tests/test_setup.py compares the two bit for bit)
+    and arrives with sorted rows."""
+    L = len(rX)
+    rfp = [None] * L
+    rfp[L - 1] = rX[L - 1]
+    l = L - 2
+    while l >= 0 and _is_identity(rfp[l + 1]):           # products with the identity are skipped, as before
+        rfp[l] = rX[l]
+        l -= 1
+    if l >= 0 and _setup_native.available() and sp.issparse(rfp[l + 1]):
+        A0 = sp.csr_matrix(rfp[l + 1])
+        factors = [sp.csr_matrix(rX[k]) for k in range(l, -1, -1)]
+        chain = _setup_native.compose_chain(A0, factors)
+        if chain is not None:
+            for k, M in zip(range(l, -1, -1), chain):
+                rfp[k] = M
+            return rfp
+    for k in range(l, -1, -1):
+        rfp[k] = _matmat(rfp[k + 1], rX[k])
+    return rfp
+
+
 def _compose_R(subspaces: Dict[str, List[Any]], refine: Dict[str, List[Any]]):
     """reference: src/multigrid.jl:192-204.  The cumulative products level->fine are shared between the
     symbols that ride the same refine ladder (`full`, `uniform` and the riders do), identity subspaces are
-    not multiplied, and a single all-ones column is a row sum: same matrices, a fraction of the setup time."""
+    not multiplied, and a single all-ones column is a row sum: same matrices, a fraction of the setup time.
+    Distinct ladders (full / dirichlet) are independent: with the native chain they are composed on two threads."""
     out = {}
-    ladders: Dict[int, List[Any]] = {}
+    distinct: Dict[int, List[Any]] = {}
+    for X in subspaces:
+        distinct.setdefault(id(refine[X]), refine[X])
+    if len(distinct) > 1 and _setup_native.available():
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(distinct), 4)) as pool:
+            ladders = dict(zip(distinct.keys(), pool.map(_ladder, distinct.values())))
+    else:
+        ladders = {k: _ladder(v) for k, v in distinct.items()}
     for X in subspaces:
         rX, sX = refine[X], subspaces[X]
         L = len(rX)
-        rfp = ladders.get(id(rX))
-        if rfp is None:
-            rfp = [None] * L
-            rfp[L - 1] = rX[L - 1]
-            for l in range(L - 2, -1, -1):
-                rfp[l] = rX[l] if _is_identity(rfp[l + 1]) else _matmat(rfp[l + 1], rX[l])
-            ladders[id(rX)] = rfp
+        rfp = ladders[id(rX)]
         ops = []
         for l in range(L):
             S = sX[l]

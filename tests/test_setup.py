@@ -319,18 +319,30 @@ def test_native_setup_helpers_are_bitwise_their_python_twins():
     w2 = wide.copy(); w2.has_sorted_indices = False; w2.sort_indices()
     assert nat.csr_sort_rows(wide) and np.array_equal(wide.indices, w2.indices) and np.array_equal(wide.data, w2.data)
     # the whole ladder, native helpers against the Python twins (fresh interpreter state is not needed: the switch is read per call)
-    g = m.subdivide(m.fem2d_P2(), 4)
-    mg_nat = m.amg(g)
-    nat._LIB, nat._TRIED = None, True                                # force the twins
-    try:
-        mg_py = m.amg(g)
-    finally:
-        nat._TRIED = False
-    for sym in mg_nat.R:
-        for a, b in zip(mg_nat.R[sym], mg_py.R[sym]):
-            a, b = sp.csr_matrix(a), sp.csr_matrix(b)
-            assert a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
-            assert np.array_equal(a.data, b.data)
+    # (the ladder composition runs as a C++ chain on scipy's storage order, two ladders on two threads: multigrid._ladder)
+    for g in (m.subdivide(m.fem2d_P2(), 4), m.subdivide(m.fem3d(k=1), 3), m.subdivide(m.fem2d_P1(), 4)):
+        mg_nat = m.amg(g)
+        nat._LIB, nat._TRIED = None, True                            # force the twins
+        try:
+            mg_py = m.amg(g)
+        finally:
+            nat._TRIED = False
+        for sym in mg_nat.R:
+            for a, b in zip(mg_nat.R[sym], mg_py.R[sym]):
+                a, b = sp.csr_matrix(a), sp.csr_matrix(b)
+                assert a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+                assert np.array_equal(a.data, b.data)
+    # the chain alone against scipy, with an exact cancellation (dropped like scipy drops it) and an empty factor row
+    A0 = sp.csr_matrix(np.array([[1.0, 1.0, 0.0], [2.0, 0.0, 0.5], [0.0, 0.0, 0.0]]))
+    B1 = sp.csr_matrix(np.array([[1.0, 3.0], [-1.0, 4.0], [0.0, 0.0]]))
+    B2 = sp.random(2, 5, density=0.7, random_state=1, format="csr")
+    got = nat.compose_chain(A0, [B1, B2])
+    C1 = A0 @ B1
+    C2 = C1 @ B2
+    for g_, w_ in zip(got, (C1, C2)):
+        w_ = w_.copy(); w_.sort_indices(); w_.eliminate_zeros()
+        assert np.array_equal(g_.indptr, w_.indptr) and np.array_equal(g_.indices, w_.indices) and np.array_equal(g_.data, w_.data)
+    assert got[0].nnz == 3 and got[0][0, 0] == 0.0 and got[0][0, 1] == 7.0
 
 
 def test_upper_bound_product_is_bitwise_scipys():
