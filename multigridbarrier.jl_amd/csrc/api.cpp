@@ -1,6 +1,7 @@
 // api.cpp -- extern "C" surface of libmgbhip.so (include/mgbhip.h).  Every entry point
 // converts C++ exceptions to a status code + mgbhip_last_error(); nothing here computes on
 // the CPU: a missing / failing GPU is an error, never a fallback.
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <algorithm>
@@ -66,11 +67,15 @@ const char* mgbhip_version(void) { return "mgbhip 0.1 (gfx950)"; }
 int mgbhip_create(mgbhip_ctx** out, int device_id, void* hip_stream) {
     MGB_API_BEGIN
     MGB_REQUIRE(out != nullptr, "null output pointer");
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    const bool dbg2 = [] { const char* e = getenv("MGBHIP_DEBUG"); return e && atoi(e) >= 2; }();
     int count = 0;
     MGB_HIP_CHECK(hipGetDeviceCount(&count));
     MGB_REQUIRE(count > 0, "no HIP device visible: this library has no CPU fallback");
     MGB_REQUIRE(device_id >= 0 && device_id < count, "device id out of range");
     MGB_HIP_CHECK(hipSetDevice(device_id));
+    if (dbg2) fprintf(stderr, "[mgbhip] create: device selected after %.3f s\n", since());
     mgbhip_ctx* c = new mgbhip_ctx();
     c->device = device_id;
     if (hip_stream) {
@@ -80,6 +85,7 @@ int mgbhip_create(mgbhip_ctx** out, int device_id, void* hip_stream) {
         c->own_stream = true;
     }
     c->timers.stream = c->stream;
+    if (dbg2) fprintf(stderr, "[mgbhip] create: stream ready after %.3f s\n", since());
     *out = c;
     return MGBHIP_OK;
     MGB_API_END
