@@ -1038,6 +1038,8 @@ __global__ __launch_bounds__(256) void fill_kernel(double value, double* __restr
 // Row-owner gather: every structural nonzero of R'HR sums its contributions from the
 // element-block slab in a fixed order -- no atomics (the reference's CUDA path uses fp64
 // atomics, ext/MultiGridBarrierCUDAExt/block_ops.jl:229-249).
+// cidx == nullptr: the slab is already in list order (projected levels: the projection kernels scatter through
+// PanelParams::spos, so a list is a contiguous run and the gather streams it).
 // qmap (optional): the positions to assemble -- the Newton loop forms the UPPER triangle only (`symmetric(H)` and the
 // factorization read nothing else, mf_analysis.cpp), nq of the nnz structural nonzeros.
 __global__ __launch_bounds__(256) void gather_assemble_kernel(int64_t nq, const int32_t* __restrict__ qmap,
@@ -1051,12 +1053,12 @@ __global__ __launch_bounds__(256) void gather_assemble_kernel(int64_t nq, const 
     const int32_t beg = cptr[q], end = cptr[q + 1];
     if (end - beg <= 4) {              // a handful of element contributions: nothing to compensate
         double s = 0.0;
-        for (int32_t t = beg; t < end; ++t) s += slab[cidx[t]];
+        for (int32_t t = beg; t < end; ++t) s += slab[cidx ? cidx[t] : t];
         Hval[q] = s;
         return;
     }
     DSum a;
-    for (int32_t t = beg; t < end; ++t) a.add(slab[cidx[t]]);
+    for (int32_t t = beg; t < end; ++t) a.add(slab[cidx ? cidx[t] : t]);
     Hval[q] = a.value();
 }
 
@@ -1104,7 +1106,7 @@ __global__ __launch_bounds__(256) void gather_assemble_wave_kernel(int64_t nq, c
     if (qi >= nq) return;
     const int64_t q = qmap ? qmap[qi] : qi;
     DSum a;
-    for (int32_t t = cptr[q] + lane; t < cptr[q + 1]; t += 64) a.add(slab[cidx[t]]);
+    for (int32_t t = cptr[q] + lane; t < cptr[q + 1]; t += 64) a.add(slab[cidx ? cidx[t] : t]);
     dsum_wave_reduce(a);
     if (lane == 0) Hval[q] = a.value();
 }
@@ -1128,10 +1130,10 @@ __global__ __launch_bounds__(256) void gather_assemble_chunk_kernel(int64_t nq, 
     DSum a;
     for (int32_t t = beg + lane; t < end; t += 256) {      // four loads in flight per lane
         const int32_t t1 = t + 64, t2 = t + 128, t3 = t + 192;
-        const double a0 = slab[cidx[t]];
-        const double a1 = t1 < end ? slab[cidx[t1]] : 0.0;
-        const double a2 = t2 < end ? slab[cidx[t2]] : 0.0;
-        const double a3 = t3 < end ? slab[cidx[t3]] : 0.0;
+        const double a0 = slab[cidx ? cidx[t] : t];
+        const double a1 = t1 < end ? slab[cidx ? cidx[t1] : t1] : 0.0;
+        const double a2 = t2 < end ? slab[cidx ? cidx[t2] : t2] : 0.0;
+        const double a3 = t3 < end ? slab[cidx ? cidx[t3] : t3] : 0.0;
         a.add(a0); a.add(a1); a.add(a2); a.add(a3);
     }
     dsum_wave_reduce(a);
@@ -1163,7 +1165,6 @@ __global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P)
     double* tmp = sh + (size_t)wave * p * P.cmax;
     const int32_t base = P.ecol_ptr[e * nu];
     const int32_t ct = P.ecol_ptr[(e + 1) * nu] - base;
-    double* out = P.slab + P.eoff[e];
     for (int a = 0; a < nu; ++a) {
         const int32_t oa = P.ecol_ptr[e * nu + a], ca = P.ecol_ptr[e * nu + a + 1] - oa;
         const double* pa = P.panels + (int64_t)p * oa;
@@ -1187,7 +1188,8 @@ __global__ __launch_bounds__(256) void panel_project_kernel(const PanelParams P)
                 if (P.upper_only && a == b && ia > ib) continue;
                 double acc = 0.0;
                 for (int rr = 0; rr < p; ++rr) acc += pa[rr + p * ia] * tmp[rr + p * ib];
-                out[(oa - base + ia) + (int64_t)ct * (ob - base + ib)] = acc;
+                const int64_t o = P.eoff[e] + (oa - base + ia) + (int64_t)ct * (ob - base + ib);
+                P.slab[P.spos ? P.spos[o] : o] = acc;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1400,7 +1402,7 @@ __global__ __launch_bounds__(256) void panel_project_staged_kernel(const PanelPa
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double* out = P.slab + P.eoff[e];
+    const int64_t eo = P.eoff[e];
     if (P.upper_only) {                     // the Newton loop reads entries i <= j only (the element's columns are sorted)
         for (int t = lane; t < ct * (ct + 1) / 2; t += 64) {
             int j = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -1410,7 +1412,8 @@ __global__ __launch_bounds__(256) void panel_project_staged_kernel(const PanelPa
             const int a = sl[i];
             double acc = 0.0;
             for (int rr = 0; rr < p; ++rr) acc += Pl[rr + p * i] * Tl[(a * p + rr) + nrow * j];
-            out[i + ct * j] = acc;
+            const int64_t o = eo + i + ct * j;
+            P.slab[P.spos ? P.spos[o] : o] = acc;
         }
         return;
     }
@@ -1422,8 +1425,132 @@ __global__ __launch_bounds__(256) void panel_project_staged_kernel(const PanelPa
         const int a = sl[i];
         double acc = 0.0;
         for (int rr = 0; rr < p; ++rr) acc += Pl[rr + p * i] * Tl[(a * p + rr) + nrow * j];
-        out[t] = acc;                       // out[i + ct * j]
+        P.slab[P.spos ? P.spos[eo + t] : eo + t] = acc;                       // entry i + ct * j of the element's block
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Projection on the matrix cores (round 4).  The loop kernels above spend their time decoding flat indices and on two LDS
+// reads per multiply-add; the arithmetic itself is two small dense products per element and state pair (a, b),
+//     U = Hel_ab * P_b   (p x c_b)      and      B_ab = P_a' U   (c_a x c_b, K = p),
+// i.e. 16 x 16 tiles of v_mfma_f64_16x16x4 with K = p padded to a multiple of 4.  The element's columns are laid out with
+// every state's range padded to a multiple of 16, so a tile belongs to one state; `cmap` takes a padded column back to the
+// element's compact index, -1 for padding.  One workgroup per element, its four waves share the tile pairs I <= J; U never
+// touches LDS: register r of the first product's result, D[i = fk + 4 r][j = fr], IS the second product's B operand of
+// k-step r (B[k = 4 r + fk][j = fr]).  LDS holds P and the element block only (13 KB at 96 padded columns: eight
+// workgroups per compute unit; a first version that staged T = Hel P kept three, and the launch is latency-bound:
+// processing several elements per workgroup in sequence was slower still).
+// Operand convention of the instruction as used throughout this library (mf_numeric.hip): lane (fr = lane & 15,
+// fk = lane >> 4) supplies A[i = fr][k = fk] and B[k = fk][j = fr]; afterwards register r holds D[i = fk + 4 r][j = fr].
+typedef double pp_double4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int pp_round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+struct PanelMfmaLayout {          // LDS layout in doubles (host and device agree through this one function)
+    int ppad, KP, NR, HC, oP, oH, oC, total;
+};
+__host__ __device__ inline PanelMfmaLayout panel_mfma_layout(int p, int nu, int ctpad) {
+    PanelMfmaLayout L;
+    L.ppad = pp_round_up(p, 4);
+    L.KP = L.ppad + 1;                               // leading dimension of P (k fastest)
+    L.NR = nu * p + 1;                               // leading dimension of the symmetric element block (row fastest)
+    L.HC = nu * L.ppad;                              // its columns: state b, k padded (zeros)
+    L.oP = 0;
+    L.oH = L.oP + L.KP * ctpad;
+    L.oC = L.oH + L.NR * L.HC;
+    L.total = L.oC + (ctpad + 1) / 2 + 8;            // cmap: ctpad int32
+    return L;
+}
+
+__global__ __launch_bounds__(256) void panel_project_mfma_kernel(const PanelParams P, int32_t ctpad_max) {
+    extern __shared__ double sh[];
+    static_assert(MGBHIP_MAX_NU == 4, "the state offsets below are written out for four states");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t e = blockIdx.x;
+    const int p = P.p, nu = P.nu, pp = p * p;
+    const int nblk = nu * (nu + 1) / 2;
+    const PanelMfmaLayout Y = panel_mfma_layout(p, nu, ctpad_max);
+    double* Pl = sh + Y.oP;
+    double* Hf = sh + Y.oH;
+    int32_t* cmap = reinterpret_cast<int32_t*>(sh + Y.oC);
+    // compact (c) and padded (q) start of every state's column range, as scalars (an indexed array would live in scratch)
+    const int32_t* ec = P.ecol_ptr + e * nu;
+    const int32_t cbase = ec[0];
+    const int w0 = ec[1] - cbase, w1 = nu > 1 ? ec[2] - ec[1] : 0, w2 = nu > 2 ? ec[3] - ec[2] : 0, w3 = nu > 3 ? ec[4] - ec[3] : 0;
+    const int c1 = w0, c2 = c1 + w1, c3 = c2 + w2, ct = c3 + w3;
+    const int q1 = pp_round_up(w0, 16), q2 = q1 + pp_round_up(w1, 16), q3 = q2 + pp_round_up(w2, 16), ctpad = q3 + pp_round_up(w3, 16);
+    const int nJt = ctpad / 16;                      // ctpad <= ctpad_max by construction of the launch
+    auto state_of_padded = [&](int jp) { return (jp >= q1 && nu > 1) + (jp >= q2 && nu > 2) + (jp >= q3 && nu > 3); };
+    auto qoff = [&](int a) { return a == 0 ? 0 : a == 1 ? q1 : a == 2 ? q2 : q3; };
+    auto coff = [&](int a) { return a == 0 ? 0 : a == 1 ? c1 : a == 2 ? c2 : c3; };
+    auto wid = [&](int a) { return a == 0 ? w0 : a == 1 ? w1 : a == 2 ? w2 : w3; };
+    // ---- stage: P in gather form (zeros in the padding), the symmetric element block (zero padding columns), cmap -----
+    const double* pan = P.panels + (int64_t)p * cbase;
+    for (int t = tid; t < Y.KP * ctpad; t += 256) {
+        const int jp = t / Y.KP, k = t - jp * Y.KP;
+        const int a = state_of_padded(jp);
+        const int ia = jp - qoff(a);
+        const bool real = k < p && ia < wid(a);
+        Pl[t] = real ? pan[k + p * (coff(a) + ia)] : 0.0;
+        if (k == 0) cmap[jp] = ia < wid(a) ? coff(a) + ia : -1;
+    }
+    for (int t = tid; t < Y.NR * Y.HC; t += 256) Hf[t] = 0.0;
+    __syncthreads();
+    for (int t = tid; t < nblk * pp; t += 256) {
+        const int blk = t / pp, q = t - blk * pp;
+        const int ss = q / p, rr = q - ss * p;       // Hel_ab[rr + p ss], a <= b
+        int a = 0, rem = blk;
+        while (rem >= nu - a) { rem -= nu - a; ++a; }
+        const int b = a + rem;
+        const double v = P.hel[((int64_t)blk * P.N + e) * (int64_t)pp + q];
+        Hf[(a * p + rr) + Y.NR * (b * Y.ppad + ss)] = v;
+        if (a != b) Hf[(b * p + ss) + Y.NR * (a * Y.ppad + rr)] = v;
+    }
+    __syncthreads();
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ksteps = Y.ppad / 4;                   // <= 16 (p <= 64)
+    const int64_t eo = P.eoff[e];
+    // ---- tile pairs I <= J: U = Hel_ab P_J (p x 16, in the accumulators), B = P_I' U --------------------------------
+    const int npair = nJt * (nJt + 1) / 2;
+    for (int tile = wave; tile < npair; tile += 4) {
+        int J = 0, rem = tile;
+        while (rem > J) { rem -= J + 1; ++J; }
+        const int I = rem;                           // I <= J
+        const int a = state_of_padded(16 * I), b = state_of_padded(16 * J);
+        pp_double4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int rt = 0; rt < ksteps; rt += 4) {     // 16 rows of U at a time: rows 4 rt .. 4 rt + 15 of the p (padded) rows
+            pp_double4 u = {0.0, 0.0, 0.0, 0.0};
+            const int urow = 4 * rt + fr;            // A operand row of U's tile
+            for (int kk = 0; kk < ksteps; ++kk)
+                u = __builtin_amdgcn_mfma_f64_16x16x4f64(urow < p ? Hf[(a * p + urow) + Y.NR * (b * Y.ppad + 4 * kk + fk)] : 0.0,
+                                                        Pl[(4 * kk + fk) + Y.KP * (16 * J + fr)], u, 0, 0, 0);
+            // u[r] = U[4 rt + fk + 4 r][j = fr]: the B operand of k-step rt + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (rt + r < ksteps)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pl[(4 * (rt + r) + fk) + Y.KP * (16 * I + fr)], u[r], acc, 0, 0, 0);
+        }
+        const int cj = cmap[16 * J + fr];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = cmap[16 * I + fk + 4 * r];
+            if (ci < 0 || cj < 0) continue;
+            if (ci <= cj) {
+                const int64_t o = eo + ci + (int64_t)ct * cj;
+                P.slab[P.spos ? P.spos[o] : o] = acc[r];
+            }
+            if (!P.upper_only && (I != J ? true : ci > cj)) {      // the other triangle: mirror of an off-diagonal tile, or
+                const int64_t o = I != J ? eo + cj + (int64_t)ct * ci : eo + ci + (int64_t)ct * cj;   // the lower half of a diagonal one
+                P.slab[P.spos ? P.spos[o] : o] = acc[r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void invert_lists_kernel(const int32_t* __restrict__ cidx, int64_t total, int32_t* __restrict__ spos) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < total) spos[cidx[t]] = (int32_t)t;
 }
 
 template <int NY>
@@ -1855,6 +1982,32 @@ void launch_panel_project_staged(const PanelParams& P, int32_t ctmax, hipStream_
         (void)hipGetLastError();
     });
     hipLaunchKernelGGL(panel_project_staged_kernel, dim3((unsigned)((P.N + 3) / 4)), dim3(256), lds, st, P, ctmax);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
+bool launch_panel_project_mfma(const PanelParams& P, hipStream_t st) {
+    if (P.N == 0) return true;
+    if (P.nu > MGBHIP_MAX_NU || P.p > 64) return false;
+    const int ctpad = P.nu * pp_round_up(P.cmax, 16);            // every state's range padded to a tile
+    const PanelMfmaLayout Y = panel_mfma_layout(P.p, P.nu, ctpad);
+    const size_t lds = (size_t)Y.total * sizeof(double);
+    static const bool off = [] { const char* e = getenv("MGBHIP_NO_MFMA_PROJECT"); return e && e[0] == '1'; }();
+    // narrow supports (2-D hierarchies: a dozen columns per element) are faster through the staged loop kernel, four elements
+    // per workgroup (L = 9: 120 us per launch); wide ones (3-D) are not
+    if (off || lds > 64 * 1024 || ctpad < 48) return false;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)panel_project_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipGetLastError();
+    });
+    hipLaunchKernelGGL(panel_project_mfma_kernel, dim3((unsigned)P.N), dim3(256), lds, st, P, ctpad);
+    MGB_HIP_CHECK(hipGetLastError());
+    return true;
+}
+
+void launch_invert_lists(const int32_t* cidx, int64_t total, int32_t* spos, hipStream_t st) {
+    if (total <= 0) return;
+    hipLaunchKernelGGL(invert_lists_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cidx, total, spos);
     MGB_HIP_CHECK(hipGetLastError());
 }
 

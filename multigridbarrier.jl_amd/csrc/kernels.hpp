@@ -143,7 +143,14 @@ struct PanelParams {
     double* slab;
     int32_t cmax;                 // largest per-(element, state) column count
     int32_t upper_only;           // project only the entries (i <= j) of the element's block: what an upper-triangle gather reads
+    const int32_t* spos;          // [slab doubles] or nullptr: where entry (element offset + i + ct j) goes -- its place in the
+                                  // contribution list of its Hessian entry, so that the gather reads contiguous runs
 };
+// one 16 x 16 output tile per matrix-core instruction pair: T = Hel P and P' T on v_mfma_f64_16x16x4 (one wave or one
+// workgroup per element); false if the element's staging does not fit (the loop kernels above then run)
+bool launch_panel_project_mfma(const PanelParams& P, hipStream_t st);
+// spos[cidx[t]] = t for t < total (cidx is a permutation of the slab positions of a projected level)
+void launch_invert_lists(const int32_t* cidx, int64_t total, int32_t* spos, hipStream_t st);
 void launch_panel_project(const PanelParams& P, hipStream_t st);
 // small coarse levels with wide supports: element streams x chunks of the packed upper triangle of H
 // accumulated in LDS, then a fixed-order sum over the streams.  H is the dense m x m array (both

@@ -462,6 +462,7 @@ void mgbhip_problem::ensure_plan(int level) {
             build_plan_device(in, L, st);
             device_plan = true;
             if (L.direct) {          // room for the shared sums and the border column behind the slab
+                std::lock_guard<std::mutex> lock(shared_mutex);     // several selection levels may be planned at once (prepare_all)
                 d_hel.ensure((size_t)(hel_cap + L.nshared + m + 1));
                 hel_level = -1;
             }
@@ -626,11 +627,27 @@ void mgbhip_problem::ensure_plan(int level) {
     if (!selection && !L.acc && L.nnz > 0) {
         // positions of the upper triangle: `symmetric(H)` (src/newton.jl:253) and the factorization read nothing else, so the
         // Newton loop projects and gathers only those (half the slab stores, half the gather traffic)
+        // ... in COLUMN-major order (column j, rows i <= j ascending): the summands of (i, j) and (i + 1, j) sit next to each
+        // other in every element block that holds both (block entry ci + ct cj, columns sorted), so neighbouring waves of the
+        // gather share their cache lines; in row-major order every 8-byte summand was a line of its own.  The order of the
+        // POSITIONS changes, not the order inside a sum: same values.
         std::vector<int32_t> up;
-        up.reserve((size_t)(L.nnz / 2 + m));
-        for (int64_t i = 0; i < m; ++i)
-            for (int32_t q = L.hHptr[i]; q < L.hHptr[i + 1]; ++q)
-                if (L.hHcol[q] >= i) up.push_back(q);
+        {
+            std::vector<int32_t> cnt((size_t)m + 1, 0);
+            for (int64_t i = 0; i < m; ++i)
+                for (int32_t q = L.hHptr[i]; q < L.hHptr[i + 1]; ++q)
+                    if (L.hHcol[q] >= i) cnt[(size_t)L.hHcol[q] + 1]++;
+            for (int64_t j = 0; j < m; ++j) cnt[(size_t)j + 1] += cnt[(size_t)j];
+            up.resize((size_t)cnt[(size_t)m]);
+            static const bool row_major = [] { const char* e = getenv("MGBHIP_UPPER_ROW_MAJOR"); return e && e[0] == '1'; }();
+            size_t w = 0;
+            for (int64_t i = 0; i < m; ++i)
+                for (int32_t q = L.hHptr[i]; q < L.hHptr[i + 1]; ++q)
+                    if (L.hHcol[q] >= i) {
+                        if (row_major) up[w++] = q;
+                        else up[(size_t)cnt[(size_t)L.hHcol[q]]++] = q;
+                    }
+        }
         L.nup = (int64_t)up.size();
         L.upq.upload(up, st);
         MGB_HIP_CHECK(hipStreamSynchronize(st));
@@ -660,6 +677,21 @@ void mgbhip_problem::ensure_plan(int level) {
         L.panels.upload(panels.data(), panels.size(), st);
         if (ecols.empty()) { L.ecols.alloc(1); L.panels.alloc(1); }
         L.slab.alloc((size_t)std::max<int64_t>(L.slab_doubles, 1));
+        static const bool no_sorted = [] { const char* e = getenv("MGBHIP_NO_SORTED_SLAB"); return e && e[0] == '1'; }();
+        if (!L.acc && L.nnz > 0 && L.slab_doubles > 0 && !no_sorted) {
+            // Every entry of an element's projected block contributes to exactly one Hessian entry: the lists are a
+            // permutation of the slab.  Store the slab in LIST order (the projection scatters through spos, 4 B per entry)
+            // and a contribution list is a contiguous run: the gather streams it instead of fetching one cache line per
+            // 8-byte summand (fem3d L = 6 phase I, m = 1 349: 23 M summands per assembly).
+            int32_t total = 0;
+            MGB_HIP_CHECK(hipMemcpyAsync(&total, L.cptr.p + L.nnz, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            MGB_HIP_CHECK(hipStreamSynchronize(st));
+            if ((int64_t)total == L.slab_doubles) {
+                L.spos.alloc((size_t)L.slab_doubles);
+                launch_invert_lists(L.cidx.p, L.slab_doubles, L.spos.p, st);
+                L.sorted_slab = true;
+            }
+        }
         if (L.acc) {
             L.acc_copies.alloc((size_t)L.acc_waves * (size_t)(m * (m + 1) / 2));
         }
@@ -913,7 +945,7 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
             PanelParams PP;
             PP.p = p; PP.nu = nu; PP.N = N;
             PP.ecol_ptr = L.ecol_ptr.p; PP.panels = L.panels.p; PP.eoff = L.eoff.p;
-            PP.hel = d_hel.p; PP.slab = L.slab.p; PP.cmax = L.cmax;
+            PP.hel = d_hel.p; PP.slab = L.slab.p; PP.cmax = L.cmax; PP.spos = nullptr;
             // Newton loop (materialize = false with a right-hand side): only the upper triangle of H is formed
             static const bool full_h = [] { const char* e = getenv("MGBHIP_FULL_COARSE_H"); return e && e[0] == '1'; }();
             const bool upper = !materialize && rhs != nullptr && L.nup > 0 && !L.acc && !full_h;
@@ -922,11 +954,14 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
                 launch_panel_accumulate(PP, L.ecols.p, (int32_t)L.m, L.acc_waves, L.acc_split, L.acc_chunk, L.acc_ctmax,
                                         L.acc_copies.p, L.Hval.p, st);
             } else {
-                // staged variant while four workgroups still fit a CU (narrow supports: 2-D hierarchies)
-                if (panel_accumulate_lds(p, nu, L.acc_ctmax) <= 40 * 1024) launch_panel_project_staged(PP, L.acc_ctmax, st);
+                PP.spos = L.sorted_slab ? L.spos.p : nullptr;
+                // the two products of the projection on the matrix cores; the loop kernels remain for elements whose
+                // staging does not fit (staged variant while four workgroups still fit a CU: narrow supports)
+                if (launch_panel_project_mfma(PP, st)) {
+                } else if (panel_accumulate_lds(p, nu, L.acc_ctmax) <= 40 * 1024) launch_panel_project_staged(PP, L.acc_ctmax, st);
                 else launch_panel_project(PP, st);
-                launch_gather_assemble(L.nnz, L.cptr.p, L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st, L.gather_chunk, L.gather_nchunk, L.gather_part.p,
-                                       upper ? L.upq.p : nullptr, upper ? L.nup : 0);
+                launch_gather_assemble(L.nnz, L.cptr.p, L.sorted_slab ? nullptr : L.cidx.p, L.slab.p, L.Hval.p, L.long_lists, st, L.gather_chunk,
+                                       L.gather_nchunk, L.gather_part.p, upper ? L.upq.p : nullptr, upper ? L.nup : 0);
             }
         }
     }

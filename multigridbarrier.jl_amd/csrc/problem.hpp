@@ -1,5 +1,6 @@
 // problem.hpp -- device-resident image of one (AMG, Convex) pair and its per-level plans.
 #pragma once
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -52,6 +53,8 @@ struct Level {
     DevBuf<double> acc_copies;
     std::vector<int32_t> hHptr, hHcol;
     DevBuf<int32_t> Hptr, Hcol, cptr, cidx, ecol_ptr, ecols, eoff;
+    DevBuf<int32_t> spos;                 // projected levels: slab position of (element block entry) = its place in its contribution list
+    bool sorted_slab = false;             // the projection kernels scatter through spos and the gather streams contiguous runs
     DevBuf<double> Hval, panels, slab;
     int64_t slab_doubles = 0;
     int32_t cmax = 1;
@@ -142,6 +145,7 @@ struct mgbhip_problem {
     void ensure_analysis(int level);
     void ensure_direct(int level);
     void prepare_all();
+    std::mutex shared_mutex;               // prepare_all: state of the problem (not of one level) touched while levels are planned side by side
     bool prepared = false;
     void ensure_plan_dense(int level);
     double eval_f0(int level, const double* d_s, const double* d_zz, const double* d_cc);
