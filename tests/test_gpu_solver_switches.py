@@ -42,3 +42,34 @@ def test_upper_triangle_coarse_assembly_is_bitwise_the_full_one(tmp_path):
     z0, its0 = _solve(tmp_path, "upper", {})
     z1, its1 = _solve(tmp_path, "full", {"MGBHIP_FULL_COARSE_H": "1"})
     assert np.array_equal(z0, z1) and its0 == its1
+
+
+CODE3D = ("import sys, json; sys.path.insert(0, %r)\n"
+          "import numpy as np, mgb_amd as m\n"
+          "prob = m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 4), prolongator=m.amg_ruge_stuben(max_coarse=40)), p=2.0)\n"
+          "sol = m.mgb_solve(prob)\n"
+          "np.save(sys.argv[1], sol.z); print(json.dumps(int(sol.SOL_main['its'].sum())))\n") % ROOT
+
+
+def _solve3d(tmp_path, tag, env):
+    out = str(tmp_path / f"{tag}.npy")
+    r = subprocess.run([sys.executable, "-c", CODE3D, out], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.load(out), json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_coarse_assembly_layout_switches_are_bitwise_and_the_matrix_core_projection_agrees(tmp_path):
+    """Round 4 coarse assembly.  The slab of a projected level is kept in the order of the contribution lists
+    (MGBHIP_NO_SORTED_SLAB=1: element-major, gathered through the index lists) and the upper-triangle positions are summed in
+    column-major order (MGBHIP_UPPER_ROW_MAJOR=1: CSR order): both only move data, every sum keeps its terms and their order,
+    so complete solves agree bit for bit -- on a 2-D ladder (staged loop projection) and on a 3-D one (matrix-core projection,
+    wide supports).  The matrix-core projection itself (MGBHIP_NO_MFMA_PROJECT=1 restores the loop kernels) rounds
+    differently: z to 1e-10 relative, Newton counts within +-3."""
+    for solve in (_solve, _solve3d):
+        z0, its0 = solve(tmp_path, "default", {})
+        for sw in ("MGBHIP_NO_SORTED_SLAB", "MGBHIP_UPPER_ROW_MAJOR"):
+            z, its = solve(tmp_path, sw, {sw: "1"})
+            assert np.array_equal(z, z0) and its == its0, sw
+        z, its = solve(tmp_path, "loops", {"MGBHIP_NO_MFMA_PROJECT": "1"})
+        assert np.abs(z - z0).max() <= 1e-10 * max(1.0, np.abs(z0).max())
+        assert abs(its - its0) <= 3, (its, its0)
