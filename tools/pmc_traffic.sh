@@ -16,6 +16,6 @@ for k in F:
     if k in W:
         rows.append((k, 1024 * (2 * F[k]["avg"] + W[k]["avg"]), F[k]["launches"]))
 rows.sort(key=lambda r: -r[1] * r[2])
-for k, b, n in rows[:24]:
+for k, b, n in rows[:40]:
     print(f"{k:60s} launches {n:6d}  bytes/launch {b/1e6:9.2f} MB")
 PY
