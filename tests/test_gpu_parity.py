@@ -728,9 +728,12 @@ def test_config4_default_start_phase1_full_size():
     """BASELINE configs[3] at full size from the DEFAULT (infeasible) start: fem3d() Q1 p = 4, L = 6 -- phase I with
     box escalation, `_matched_t` hand-off, main ramp -- checked by invariants (no oracle run at 262 144 nodes):
     strictly feasible result, Dirichlet data exact, and a second solve on the resident image is bitwise identical
-    with the same iteration counts.  Hierarchy: max_coarse=500 (coarsest space 861 unknowns, 1 402 iterations).  On the
-    reference-default ladder phase I's initial centring ends with lambda^2 <= 0 in the coarsest space on the device and
-    in the oracle alike; with max_coarse=300 it creeps for 9 000 iterations in a 145-unknown space at cond(H) ~ 1e15,
+    with the same iteration counts.  Hierarchy: max_coarse=500 (coarsest space 861 unknowns, 1 403 iterations).  On the
+    reference-default ladder ([3, 29, 145, 861, ...]; phase I: [4, 44, 227, 1 349, ...]) phase I's initial centring bisects down
+    to the 4-unknown space and creeps there with lambda^2 = 1.9e-5 (cond(H) ~ 4e17) until maxit = 10 000, on the device
+    (tests/dev/logs/gpu_fem3d_L6_p4_default_ladder.log: every box escalation ends that way, MGBConvergenceFailure after 25 s)
+    and in the oracle (tests/dev/logs/oracle_fem3d_L6_p4_default.log: the same plateau, y equal to the device's to nine digits
+    at iterations 50, 1 550 and 3 300 -- the oracle run takes one second per iteration and was cut); with max_coarse=300 it creeps for 9 000 iterations in a 145-unknown space at cond(H) ~ 1e15,
     where the outcome is a matter of rounding (device 9 357 / oracle 9 359 iterations with plain restriction sums; H
     indefinite at iteration 5 065 with compensated ones) -- DESIGN.md section 5."""
     from mgb_amd.solve import mgb_driver
