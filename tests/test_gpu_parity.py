@@ -799,3 +799,43 @@ def test_fused_selection_prolongation_is_bitwise_the_prolongation_launch(monkeyp
     b = m.mgb_solve(prob)
     assert np.array_equal(a.z, b.z)
     assert np.array_equal(a.SOL_main["its"], b.SOL_main["its"])
+
+
+@pytest.mark.parametrize("kind", ["fem3d_k2_L3_geometric", "fem3d_k1_L4_amg"])
+def test_wide_support_projection_on_the_matrix_cores_matches_oracle(kind):
+    """Round 4: coarse levels whose elements reach >= 48 padded columns are projected with v_mfma_f64_16x16x4
+    (`panel_project_mfma_kernel`: U = Hel_ab P_b, B = P_a' U per 16 x 16 tile; K = p padded to a multiple of 4) into a slab
+    kept in contribution-list order.  Cases chosen for the kernel's corners: p = 27 (K padded to 28, two row tiles of U) with
+    two and three state variables, p = 8 with three (the phase-I image; 16 columns per state = one tile each).  Both triangles
+    (`f2`, the API path: mirrored tiles) and the Newton loop's upper-triangle path (`newton_direction`) against the oracle."""
+    if kind == "fem3d_k2_L3_geometric":
+        prob = m.assemble(m.geometric_mg(m.fem3d(k=2), 3), p=2.0)
+    else:
+        prob = m.assemble(m.amg(m.subdivide(m.fem3d(k=1), 4)), p=2.0)
+    n = prob.M[0].w.size
+    nD = len(prob.M[0].D_fine)
+    D = _device(prob)
+    rng = np.random.default_rng(11)
+    try:
+        z0 = stacked(prob.g)
+        images = [(D.main, O.OracleAMG(prob.M[0]), prob.Q, 0.1 * prob.f, z0)]
+        feas = D.feasibility
+        feas.set_box(200.0, 300.0)
+        c1 = np.zeros((n, nD + 1 + 2)); c1[:, nD] = 1.0
+        images.append((feas, O.OracleAMG(prob.M[1]), O.FeasConvex(prob.Q, 200.0, 300.0, nD + 1), c1,
+                       np.concatenate([z0, np.full(n, 150.0)])))
+        for P, Mo, Q, c, z in images:
+            _check_primitives(P, Mo, Q, c, z, rng, scale=1e-4, solve=False)
+            B = O.Barrier(Q)
+            for J in range(len(Mo.R_fine)):
+                R = Mo.R_fine[J]
+                s = 1e-4 * rng.standard_normal(R.shape[1])
+                g_o = B.f1(s, Mo.w, c, R, Mo.D_fine, z)
+                H_o = sp.csr_matrix(B.f2(s, Mo.w, c, R, Mo.D_fine, z))
+                x, lam, _ = P.newton_direction(J, s, c, z)
+                r = H_o @ x - g_o
+                bwd = np.linalg.norm(r, np.inf) / (abs(H_o).sum(axis=1).max() * np.linalg.norm(x, np.inf) + np.linalg.norm(g_o, np.inf))
+                assert bwd <= KERNEL_RTOL, (kind, J, bwd)
+                assert abs(lam - float(g_o @ x)) <= KERNEL_RTOL * abs(lam)
+    finally:
+        D.close()
