@@ -1038,8 +1038,17 @@ void mgbhip_problem::prepare_all() {
     for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
     worker();
     for (auto& t : pool) t.join();
-    for (const auto& e : errors)
-        if (e) std::rethrow_exception(e);
+    // A level that could not be prepared (its plan exceeds an index range, the device is out of memory) is left to the lazy
+    // path: the solve may never visit it (levels 8 and 9 of the L = 9 ladder are not), and if it does the error is raised there.
+    for (size_t l = 0; l < errors.size(); ++l) {
+        if (!errors[l]) continue;
+        (void)hipGetLastError();
+        if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 1) {
+            try { std::rethrow_exception(errors[l]); }
+            catch (const std::exception& ex) { fprintf(stderr, "[mgbhip] prepare: level %zu left to the lazy path (%s)\n", l, ex.what()); }
+            catch (...) { fprintf(stderr, "[mgbhip] prepare: level %zu left to the lazy path\n", l); }
+        }
+    }
 }
 
 // Direct value map (the factorization reads the element-block slab, H is never materialised) and the condensed leaves of a
