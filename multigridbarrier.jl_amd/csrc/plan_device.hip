@@ -272,4 +272,75 @@ void build_plan_device(const PlanDeviceIn& in, Level& L, hipStream_t st) {
     }
 }
 
+namespace {
+
+__global__ void expand_rows(int64_t rows, const int32_t* __restrict__ ptr, int32_t* __restrict__ rowidx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    for (int32_t q = ptr[i]; q < ptr[i + 1]; ++q) rowidx[q] = (int32_t)i;
+}
+
+__global__ void iota32(int64_t n, uint32_t* __restrict__ v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+
+// after the sort: entry d of R' is entry q = perm[d] of R; row pointers of R' from the sorted column keys
+__global__ void transpose_fill(int64_t nnz, int64_t cols, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
+                               const int32_t* __restrict__ rowidx, const double* __restrict__ Rval, int32_t* __restrict__ Tptr,
+                               int32_t* __restrict__ Tcol, double* __restrict__ Tval) {
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d >= nnz) return;
+    const uint32_t q = perm[d], c = keys[d];
+    Tcol[d] = rowidx[q];
+    Tval[d] = Rval[q];
+    const uint32_t prev = d == 0 ? 0u : keys[d - 1];
+    if (d == 0) for (uint32_t j = 0; j <= c; ++j) Tptr[j] = 0;
+    else for (uint32_t j = prev + 1; j <= c; ++j) Tptr[j] = (int32_t)d;       // rows prev+1 .. c start here (empty ones included)
+    if (d == nnz - 1) for (int64_t j = (int64_t)c + 1; j <= cols; ++j) Tptr[j] = (int32_t)nnz;
+}
+
+__global__ void max_row_length(int64_t rows, const int32_t* __restrict__ ptr, int32_t* __restrict__ out) {
+    int32_t best = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) best = max(best, ptr[i + 1] - ptr[i]);
+    atomicMax(out, best);
+}
+
+}  // namespace
+
+int32_t transpose_csr_device(int64_t rows, int64_t cols, int64_t nnz, const int32_t* Rptr, const int32_t* Rcol, const double* Rval,
+                             DevBuf<int32_t>& Tptr, DevBuf<int32_t>& Tcol, DevBuf<double>& Tval, hipStream_t st) {
+    Tptr.alloc((size_t)cols + 1);
+    Tcol.alloc((size_t)std::max<int64_t>(nnz, 1));
+    Tval.alloc((size_t)std::max<int64_t>(nnz, 1));
+    if (nnz == 0) {
+        Tptr.zero(st);
+        MGB_HIP_CHECK(hipStreamSynchronize(st));
+        return 0;
+    }
+    DevBuf<int32_t> rowidx, d_max;
+    DevBuf<uint32_t> k1, v0, v1;
+    rowidx.alloc((size_t)nnz); k1.alloc((size_t)nnz); v0.alloc((size_t)nnz); v1.alloc((size_t)nnz);
+    d_max.alloc(1);
+    d_max.zero(st, 1);
+    hipLaunchKernelGGL(expand_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows, Rptr, rowidx.p);
+    hipLaunchKernelGGL(iota32, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, v0.p);
+    unsigned bits = 1;
+    while (bits < 32 && ((uint64_t)cols >> bits) != 0) ++bits;
+    const uint32_t* k0 = reinterpret_cast<const uint32_t*>(Rcol);           // column indices are non-negative
+    size_t tmp_bytes = 0;
+    MGB_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1.p, v0.p, v1.p, (size_t)nnz, 0u, bits, st));
+    DevBuf<char> tmp;
+    tmp.alloc(tmp_bytes + 16);
+    MGB_HIP_CHECK(rocprim::radix_sort_pairs((void*)tmp.p, tmp_bytes, k0, k1.p, v0.p, v1.p, (size_t)nnz, 0u, bits, st));
+    hipLaunchKernelGGL(transpose_fill, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, cols, k1.p, v1.p, rowidx.p, Rval,
+                       Tptr.p, Tcol.p, Tval.p);
+    hipLaunchKernelGGL(max_row_length, dim3((unsigned)std::min<int64_t>((cols + 255) / 256, 1024)), dim3(256), 0, st, cols, Tptr.p, d_max.p);
+    MGB_HIP_CHECK(hipGetLastError());
+    int32_t maxrow = 0;
+    d_max.download(&maxrow, 1, st);
+    MGB_HIP_CHECK(hipStreamSynchronize(st));                                 // the sort buffers are locals
+    return maxrow;
+}
+
 }  // namespace mgbhip

@@ -34,4 +34,10 @@ int64_t plan_device_pairs(const PlanDeviceIn& in);
 // fills L.Hptr/Hcol/cptr/cidx (device), L.hHptr/hHcol (host copy for the symbolic analysis), L.nnz, L.long_lists
 void build_plan_device(const PlanDeviceIn& in, Level& L, hipStream_t st);
 
+// CSR of R' (the gather form of R' * v) from the CSR of R on the device: one stable radix sort of the entries by column,
+// so the entries of a row of R' come in ascending row order of R -- the order of the host loop this replaces.
+// Returns the longest row of R' (what decides the long-row / chunked restriction kernels).
+int32_t transpose_csr_device(int64_t rows, int64_t cols, int64_t nnz, const int32_t* Rptr, const int32_t* Rcol, const double* Rval,
+                             DevBuf<int32_t>& Tptr, DevBuf<int32_t>& Tcol, DevBuf<double>& Tval, hipStream_t st);
+
 }  // namespace mgbhip

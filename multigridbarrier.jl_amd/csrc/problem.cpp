@@ -44,20 +44,28 @@ static void upload_csr(const mgbhip_csr& R, Level& L, hipStream_t st) {
     L.Rcol.upload(L.hRcol.data(), L.hRcol.size(), st);
     L.Rval.upload(L.hRval.data(), L.hRval.size(), st);
     if (L.hRcol.empty()) { L.Rcol.alloc(1); L.Rval.alloc(1); }
-    // transpose (CSR of R') for the gather form of R' * v
-    std::vector<int32_t> tp(R.cols + 1, 0), tc(nnz);
-    std::vector<double> tv(nnz);
-    for (int64_t q = 0; q < nnz; ++q) tp[L.hRcol[q] + 1]++;
-    for (int64_t j = 0; j < R.cols; ++j) tp[j + 1] += tp[j];
-    std::vector<int32_t> fill(tp.begin(), tp.end() - 1);
+    // transpose (CSR of R') for the gather form of R' * v: on the device from the uploaded R (one stable radix sort by
+    // column: rows ascending inside a column, as the host loop it replaced produced them) -- MGBHIP_HOST_TRANSPOSE=1 keeps the
+    // host loop, which also sent the transposed arrays over PCIe (0.65 GB at L = 9)
+    static const bool host_T = [] { const char* e = getenv("MGBHIP_HOST_TRANSPOSE"); return e && e[0] == '1'; }();
+    std::vector<int32_t> tp, tc;
+    std::vector<double> tv;
     int32_t maxrow = 0;
-    for (int64_t i = 0; i < R.rows; ++i)
-        for (int32_t q = L.hRptr[i]; q < L.hRptr[i + 1]; ++q) {
-            int32_t d = fill[L.hRcol[q]]++;
-            tc[d] = (int32_t)i;
-            tv[d] = L.hRval[q];
-        }
-    for (int64_t j = 0; j < R.cols; ++j) maxrow = std::max(maxrow, tp[j + 1] - tp[j]);
+    if (host_T) {
+        tp.assign((size_t)R.cols + 1, 0); tc.resize((size_t)nnz); tv.resize((size_t)nnz);
+        for (int64_t q = 0; q < nnz; ++q) tp[L.hRcol[q] + 1]++;
+        for (int64_t j = 0; j < R.cols; ++j) tp[j + 1] += tp[j];
+        std::vector<int32_t> fill(tp.begin(), tp.end() - 1);
+        for (int64_t i = 0; i < R.rows; ++i)
+            for (int32_t q = L.hRptr[i]; q < L.hRptr[i + 1]; ++q) {
+                int32_t d = fill[L.hRcol[q]]++;
+                tc[d] = (int32_t)i;
+                tv[d] = L.hRval[q];
+            }
+        for (int64_t j = 0; j < R.cols; ++j) maxrow = std::max(maxrow, tp[j + 1] - tp[j]);
+    } else {
+        maxrow = transpose_csr_device(R.rows, R.cols, nnz, L.Rptr.p, L.Rcol.p, L.Rval.p, L.Tptr, L.Tcol, L.Tval, st);
+    }
     L.T_long = maxrow > 64;
     L.T_chunks = (maxrow >= 1024 && R.cols <= 16384) ? csr_chunks(maxrow) : 0;
     int32_t maxr = 0;
@@ -74,10 +82,12 @@ static void upload_csr(const mgbhip_csr& R, Level& L, hipStream_t st) {
             L.Rsel.upload(sel, st);
         }
     }
-    L.Tptr.upload(tp, st);
-    L.Tcol.upload(tc.data(), tc.size(), st);
-    L.Tval.upload(tv.data(), tv.size(), st);
-    if (tc.empty()) { L.Tcol.alloc(1); L.Tval.alloc(1); }
+    if (host_T) {
+        L.Tptr.upload(tp, st);
+        L.Tcol.upload(tc.data(), tc.size(), st);
+        L.Tval.upload(tv.data(), tv.size(), st);
+        if (tc.empty()) { L.Tcol.alloc(1); L.Tval.alloc(1); }
+    }
     MGB_HIP_CHECK(hipStreamSynchronize(st));
 }
 

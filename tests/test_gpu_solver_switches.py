@@ -73,3 +73,14 @@ def test_coarse_assembly_layout_switches_are_bitwise_and_the_matrix_core_project
         z, its = solve(tmp_path, "loops", {"MGBHIP_NO_MFMA_PROJECT": "1"})
         assert np.abs(z - z0).max() <= 1e-10 * max(1.0, np.abs(z0).max())
         assert abs(its - its0) <= 3, (its, its0)
+
+
+def test_device_transpose_of_the_prolongators_is_bitwise_the_host_loop(tmp_path):
+    """Round 4 (time to first solution): the CSR of R' that the restriction R' v gathers through is built on the device from
+    the uploaded R (one stable radix sort by column, csrc/plan_device.hip: transpose_csr_device) instead of by a host loop
+    whose result crossed PCIe.  Same entries in the same order inside every row of R', so every restriction sums in the same
+    order: complete solves agree bit for bit with MGBHIP_HOST_TRANSPOSE=1, on a 2-D and on a 3-D ladder."""
+    for solve in (_solve, _solve3d):
+        z0, its0 = solve(tmp_path, "device_T", {})
+        z1, its1 = solve(tmp_path, "host_T", {"MGBHIP_HOST_TRANSPOSE": "1"})
+        assert np.array_equal(z0, z1) and its0 == its1
