@@ -75,10 +75,29 @@ def _csr_ok(M) -> bool:
             and M.indptr.dtype == np.int32 and max(M.shape) < 2**31 - 1)
 
 
+class _Csr(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("cols", C.c_int64), ("ptr", C.POINTER(C.c_int32)), ("idx", C.POINTER(C.c_int32)),
+                ("val", C.POINTER(C.c_double))]
+
+
+class _Out(C.Structure):
+    _fields_ = [("nnz", C.c_int64), ("ptr", C.POINTER(C.c_int32)), ("idx", C.POINTER(C.c_int32)), ("val", C.POINTER(C.c_double))]
+
+
+def _adopt(lib, ptr, count, ctype, dtype):
+    """NumPy array over a malloc'ed buffer of the library; the buffer is released when the last view of it dies."""
+    import weakref
+    addr = C.cast(ptr, C.c_void_p).value
+    buf = (ctype * max(count, 1)).from_address(addr)
+    weakref.finalize(buf, lib.mgbsetup_free, C.c_void_p(addr))
+    return np.frombuffer(buf, dtype=dtype)[:count]
+
+
 def compose_chain(A0, factors):
     """[A0 @ B1, (A0 @ B1) @ B2, ...] with sorted rows, every product formed by scipy's own `csr_matmat` loop restated in
     C++ on the previous product in ITS storage order (see csrc/setup_host.cpp) -- entry for entry what
-    `C = C @ B; D = C.copy(); D.sort_indices()` gives.  Returns None when the library or the operands do not qualify."""
+    `C = C @ B; D = C.copy(); D.sort_indices()` gives.  One library call: product k + 1 is formed while product k is copied
+    out and sorted on a second thread.  Returns None when the library or the operands do not qualify."""
     import scipy.sparse as sp
     lib = _lib()
     if lib is None or not _csr_ok(A0) or not all(_csr_ok(B) for B in factors):
@@ -87,31 +106,44 @@ def compose_chain(A0, factors):
     lib.mgbsetup_chain_create.restype = C.c_void_p
     lib.mgbsetup_chain_create.argtypes = [C.c_int64, C.c_int64, ip, ip, dp]
     lib.mgbsetup_chain_destroy.argtypes = [C.c_void_p]
-    lib.mgbsetup_chain_multiply.restype = C.c_int64
-    lib.mgbsetup_chain_multiply.argtypes = [C.c_void_p, C.c_int64, C.c_int64, ip, ip, dp]
-    lib.mgbsetup_chain_emit_sorted.argtypes = [C.c_void_p, ip, ip, dp]
+    lib.mgbsetup_chain_run.restype = C.c_int64
+    lib.mgbsetup_chain_run.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_Csr), C.POINTER(_Out)]
+    lib.mgbsetup_free.argtypes = [C.c_void_p]
+    lib.mgbsetup_free.restype = None
     rows = A0.shape[0]
-    idx0 = A0.indices if A0.nnz else np.zeros(1, dtype=np.int32)
-    val0 = A0.data if A0.nnz else np.zeros(1)
-    h = lib.mgbsetup_chain_create(rows, A0.shape[1], A0.indptr.ctypes.data_as(ip), idx0.ctypes.data_as(ip), val0.ctypes.data_as(dp))
+    z32, z64 = np.zeros(1, dtype=np.int32), np.zeros(1)
+    keep = []
+
+    def arrs(M):
+        idx = M.indices if M.nnz else z32
+        val = M.data if M.nnz else z64
+        keep.extend([M.indptr, idx, val])
+        return M.indptr.ctypes.data_as(ip), idx.ctypes.data_as(ip), val.ctypes.data_as(dp)
+
+    h = lib.mgbsetup_chain_create(rows, A0.shape[1], *arrs(A0))
     if not h:
         return None
-    out = []
+    K = len(factors)
+    fac = (_Csr * max(K, 1))()
+    outs = (_Out * max(K, 1))()
+    for k, B in enumerate(factors):
+        fac[k].rows, fac[k].cols = B.shape
+        fac[k].ptr, fac[k].idx, fac[k].val = arrs(B)
     try:
-        for B in factors:
-            bj = B.indices if B.nnz else np.zeros(1, dtype=np.int32)
-            bx = B.data if B.nnz else np.zeros(1)
-            nnz = lib.mgbsetup_chain_multiply(h, B.shape[0], B.shape[1], B.indptr.ctypes.data_as(ip), bj.ctypes.data_as(ip), bx.ctypes.data_as(dp))
-            if nnz < 0:
-                return None
-            indptr = np.empty(rows + 1, dtype=np.int32)
-            indices = np.empty(max(nnz, 1), dtype=np.int32)
-            data = np.empty(max(nnz, 1), dtype=np.float64)
-            if lib.mgbsetup_chain_emit_sorted(h, indptr.ctypes.data_as(ip), indices.ctypes.data_as(ip), data.ctypes.data_as(dp)) != 0:
-                return None
-            M = sp.csr_matrix((data[:nnz], indices[:nnz], indptr), shape=(rows, B.shape[1]), copy=False)
-            M.has_sorted_indices = True
-            out.append(M)
+        rc = lib.mgbsetup_chain_run(h, K, fac, outs)
     finally:
         lib.mgbsetup_chain_destroy(h)
-    return out
+    mats = []
+    for k in range(K):                                   # adopt every buffer that was handed out, also on failure
+        if not outs[k].ptr:
+            continue
+        nnz = int(outs[k].nnz)
+        indptr = _adopt(lib, outs[k].ptr, rows + 1, C.c_int32, np.int32)
+        indices = _adopt(lib, outs[k].idx, nnz, C.c_int32, np.int32)
+        data = _adopt(lib, outs[k].val, nnz, C.c_double, np.float64)
+        M = sp.csr_matrix((data, indices, indptr), shape=(rows, factors[k].shape[1]), copy=False)
+        M.has_sorted_indices = True
+        mats.append(M)
+    if rc != 0 or len(mats) != K:
+        return None
+    return mats

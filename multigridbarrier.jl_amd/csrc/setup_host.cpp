@@ -6,6 +6,9 @@
 #include <algorithm>
 #include <climits>
 #include <cstdint>
+#include <cstdlib>
+#include <memory>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -138,20 +141,20 @@ void* mgbsetup_chain_create(int64_t rows, int64_t cols, const int32_t* ptr, cons
 
 void mgbsetup_chain_destroy(void* h) { delete static_cast<Chain*>(h); }
 
-// C <- C * B (B: brows x bcols CSR, brows == cols of C).  Returns the number of stored entries of the product, -1 on a shape
-// mismatch, -2 if the product exceeds 32-bit indexing.
-int64_t mgbsetup_chain_multiply(void* h, int64_t brows, int64_t bcols, const int32_t* Bp, const int32_t* Bj, const double* Bx) {
-    Chain* c = static_cast<Chain*>(h);
-    if (!c || brows != c->cols || bcols < 0 || !Bp) return -1;
-    std::vector<int32_t> next((size_t)bcols, -1), np((size_t)c->rows + 1, 0), nj;
-    std::vector<double> sums((size_t)bcols, 0.0), nx;
-    nj.reserve(c->idx.size() + c->idx.size() / 4);
-    nx.reserve(c->idx.size() + c->idx.size() / 4);
-    for (int64_t i = 0; i < c->rows; ++i) {
+// A * B with scipy's kernel (see above); false if the product exceeds 32-bit indexing
+static bool chain_product(const Chain& A, int64_t bcols, const int32_t* Bp, const int32_t* Bj, const double* Bx, Chain& out) {
+    std::vector<int32_t> next((size_t)bcols, -1);
+    std::vector<double> sums((size_t)bcols, 0.0);
+    out.rows = A.rows; out.cols = bcols;
+    out.ptr.assign((size_t)A.rows + 1, 0);
+    out.idx.clear(); out.val.clear();
+    out.idx.reserve(A.idx.size() + A.idx.size() / 4);
+    out.val.reserve(A.idx.size() + A.idx.size() / 4);
+    for (int64_t i = 0; i < A.rows; ++i) {
         int32_t head = -2, length = 0;
-        for (int32_t jj = c->ptr[i]; jj < c->ptr[i + 1]; ++jj) {
-            const int32_t j = c->idx[jj];
-            const double v = c->val[jj];
+        for (int32_t jj = A.ptr[i]; jj < A.ptr[i + 1]; ++jj) {
+            const int32_t j = A.idx[jj];
+            const double v = A.val[jj];
             for (int32_t kk = Bp[j]; kk < Bp[j + 1]; ++kk) {
                 const int32_t k = Bj[kk];
                 sums[k] += v * Bx[kk];
@@ -159,17 +162,26 @@ int64_t mgbsetup_chain_multiply(void* h, int64_t brows, int64_t bcols, const int
             }
         }
         for (int32_t t = 0; t < length; ++t) {
-            if (sums[head] != 0) { nj.push_back(head); nx.push_back(sums[head]); }
+            if (sums[head] != 0) { out.idx.push_back(head); out.val.push_back(sums[head]); }
             const int32_t tmp = head;
             head = next[head];
             next[tmp] = -1;
             sums[tmp] = 0;
         }
-        if (nj.size() >= (size_t)INT32_MAX) return -2;
-        np[(size_t)i + 1] = (int32_t)nj.size();
+        if (out.idx.size() >= (size_t)INT32_MAX) return false;
+        out.ptr[(size_t)i + 1] = (int32_t)out.idx.size();
     }
-    c->ptr.swap(np); c->idx.swap(nj); c->val.swap(nx);
-    c->cols = bcols;
+    return true;
+}
+
+// C <- C * B (B: brows x bcols CSR, brows == cols of C).  Returns the number of stored entries of the product, -1 on a shape
+// mismatch, -2 if the product exceeds 32-bit indexing.
+int64_t mgbsetup_chain_multiply(void* h, int64_t brows, int64_t bcols, const int32_t* Bp, const int32_t* Bj, const double* Bx) {
+    Chain* c = static_cast<Chain*>(h);
+    if (!c || brows != c->cols || bcols < 0 || !Bp) return -1;
+    Chain out;
+    if (!chain_product(*c, bcols, Bp, Bj, Bx, out)) return -2;
+    *c = std::move(out);
     return (int64_t)c->idx.size();
 }
 
@@ -185,6 +197,41 @@ int mgbsetup_chain_emit_sorted(void* h, int32_t* ptr, int32_t* idx, double* val)
         std::copy(c->val.begin(), c->val.end(), val);
     }
     return mgbsetup_csr_sort_rows(c->rows, ptr, idx, val);
+}
+
+// The whole ladder in one call: product k+1 is formed while product k is copied out and sorted on a second thread (both only
+// read product k).  outs[k] receives malloc'ed arrays (ptr: rows + 1, idx / val: nnz[k]) that the caller releases with
+// mgbsetup_free.  Returns 0, or the negative code of mgbsetup_chain_multiply.
+struct MgbSetupCsr { int64_t rows, cols; const int32_t* ptr; const int32_t* idx; const double* val; };
+struct MgbSetupOut { int64_t nnz; int32_t* ptr; int32_t* idx; double* val; };
+
+void mgbsetup_free(void* p) { std::free(p); }
+
+int64_t mgbsetup_chain_run(void* h, int32_t nfac, const MgbSetupCsr* fac, MgbSetupOut* outs) {
+    Chain* c = static_cast<Chain*>(h);
+    if (!c || nfac < 0 || (nfac > 0 && (!fac || !outs))) return -1;
+    std::vector<std::unique_ptr<Chain>> prods;           // product k stays alive while its emitter and product k + 1 read it
+    std::vector<std::thread> emitters;
+    int64_t rc = 0;
+    const Chain* prev = c;
+    for (int32_t k = 0; k < nfac; ++k) {
+        if (fac[k].rows != prev->cols || fac[k].cols < 0 || !fac[k].ptr) { rc = -1; break; }
+        prods.emplace_back(new Chain());
+        Chain* cur = prods.back().get();
+        if (!chain_product(*prev, fac[k].cols, fac[k].ptr, fac[k].idx, fac[k].val, *cur)) { rc = -2; break; }
+        const int64_t nnz = (int64_t)cur->idx.size();
+        MgbSetupOut* o = &outs[k];
+        o->nnz = nnz;
+        o->ptr = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (size_t)(cur->rows + 1)));
+        o->idx = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
+        o->val = static_cast<double*>(std::malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
+        if (!o->ptr || !o->idx || !o->val) { rc = -3; break; }
+        emitters.emplace_back([cur, o] { mgbsetup_chain_emit_sorted(cur, o->ptr, o->idx, o->val); });
+        prev = cur;
+    }
+    for (auto& t : emitters) t.join();
+    if (rc == 0 && !prods.empty()) *c = std::move(*prods.back());
+    return rc;
 }
 
 }  // extern "C"

@@ -215,6 +215,20 @@ def _ladder(rX: List[Any]) -> List[Any]:
     return rfp
 
 
+_PREFETCHED: Dict[int, Any] = {}        # id(refine list) -> (the list, Future of its ladder): see prefetch_ladder
+
+
+def prefetch_ladder(rX: List[Any]) -> None:
+    """Start composing the ladder of `rX` on a background thread (the C++ chain runs without the interpreter lock) while the
+    caller goes on building the next hierarchy in Python; `_compose_R` picks the result up.  No-op without libmgbsetup.so."""
+    if not _setup_native.available():
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1)
+    _PREFETCHED[id(rX)] = (rX, pool.submit(_ladder, rX))
+    pool.shutdown(wait=False)
+
+
 def _compose_R(subspaces: Dict[str, List[Any]], refine: Dict[str, List[Any]]):
     """reference: src/multigrid.jl:192-204.  The cumulative products level->fine are shared between the
     symbols that ride the same refine ladder (`full`, `uniform` and the riders do), identity subspaces are
@@ -224,12 +238,23 @@ def _compose_R(subspaces: Dict[str, List[Any]], refine: Dict[str, List[Any]]):
     distinct: Dict[int, List[Any]] = {}
     for X in subspaces:
         distinct.setdefault(id(refine[X]), refine[X])
-    if len(distinct) > 1 and _setup_native.available():
+    ladders: Dict[int, List[Any]] = {}
+    futures: Dict[int, Any] = {}
+    for k, v in list(distinct.items()):                  # ladders a caller started earlier (prefetch_ladder): still running, maybe
+        pre = _PREFETCHED.pop(k, None)
+        if pre is not None and pre[0] is v:
+            futures[k] = pre[1]
+            del distinct[k]
+    if distinct and (len(distinct) + len(futures)) > 1 and _setup_native.available():
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(len(distinct), 4)) as pool:
-            ladders = dict(zip(distinct.keys(), pool.map(_ladder, distinct.values())))
+        pool = ThreadPoolExecutor(max_workers=min(len(distinct), 4))
+        for k, v in distinct.items():
+            futures[k] = pool.submit(_ladder, v)
+        pool.shutdown(wait=False)
     else:
-        ladders = {k: _ladder(v) for k, v in distinct.items()}
+        ladders.update({k: _ladder(v) for k, v in distinct.items()})
+    for k, fut in futures.items():
+        ladders[k] = fut.result()
     for X in subspaces:
         rX, sX = refine[X], subspaces[X]
         L = len(rX)
@@ -333,13 +358,19 @@ def assemble_amg_dicts(geom: Geometry, n_doubled: int,
         sub[L_full - 1] = E
         subspaces[sym] = sub
         refine_d[sym] = refine_full
-    for sym, nodes in dirichlet_nodes.items():
-        if sym in subspaces:
-            raise ValueError(f"dirichlet_nodes key :{sym} is reserved; choose another symbol")
-        r, s = build_dirichlet(nodes)
-        subspaces[sym] = s
-        refine_d[sym] = r
-    return make_multigrid(geom, subspaces, refine_d)
+    prefetch_ladder(refine_full)             # composed in the background while the :dirichlet hierarchies are coarsened below
+    try:
+        for sym, nodes in dirichlet_nodes.items():
+            if sym in subspaces:
+                raise ValueError(f"dirichlet_nodes key :{sym} is reserved; choose another symbol")
+            r, s = build_dirichlet(nodes)
+            subspaces[sym] = s
+            refine_d[sym] = r
+        return make_multigrid(geom, subspaces, refine_d)
+    finally:
+        pre = _PREFETCHED.pop(id(refine_full), None)     # not consumed (stretched ladders, an error above): let it finish and drop it
+        if pre is not None:
+            pre[1].cancel()
 
 
 # ---------------------------------------------------------------------------
