@@ -143,7 +143,23 @@ def compose_chain(A0, factors):
         data = _adopt(lib, outs[k].val, nnz, C.c_double, np.float64)
         M = sp.csr_matrix((data, indices, indptr), shape=(rows, factors[k].shape[1]), copy=False)
         M.has_sorted_indices = True
+        M.has_canonical_format = True                      # sorted and duplicate-free by construction: spares scipy's scans
         mats.append(M)
     if rc != 0 or len(mats) != K:
         return None
     return mats
+
+
+def csr_row_sums(M):
+    """`np.asarray(M.sum(axis=1)).ravel()` of a CSR matrix with numpy's own association of the terms (see setup_host.cpp), or
+    None when the library or the layout does not qualify."""
+    lib = _lib()
+    if lib is None or not _csr_ok(M):
+        return None
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    lib.mgbsetup_csr_row_sums.argtypes = [C.c_int64, ip, dp, dp]
+    out = np.empty(M.shape[0])
+    val = M.data if M.nnz else np.zeros(1)
+    if lib.mgbsetup_csr_row_sums(M.shape[0], M.indptr.ctypes.data_as(ip), val.ctypes.data_as(dp), out.ctypes.data_as(dp)) != 0:
+        return None
+    return out

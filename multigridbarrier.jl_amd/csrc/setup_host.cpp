@@ -148,8 +148,12 @@ static bool chain_product(const Chain& A, int64_t bcols, const int32_t* Bp, cons
     out.rows = A.rows; out.cols = bcols;
     out.ptr.assign((size_t)A.rows + 1, 0);
     out.idx.clear(); out.val.clear();
-    out.idx.reserve(A.idx.size() + A.idx.size() / 4);
-    out.val.reserve(A.idx.size() + A.idx.size() / 4);
+    {   // candidates per row bound the product: reserve once (untouched pages cost nothing), never reallocate
+        size_t ub = 0;
+        for (size_t q = 0; q < A.idx.size(); ++q) ub += (size_t)(Bp[A.idx[q] + 1] - Bp[A.idx[q]]);
+        out.idx.reserve(ub);
+        out.val.reserve(ub);
+    }
     for (int64_t i = 0; i < A.rows; ++i) {
         int32_t head = -2, length = 0;
         for (int32_t jj = A.ptr[i]; jj < A.ptr[i + 1]; ++jj) {
@@ -197,6 +201,39 @@ int mgbsetup_chain_emit_sorted(void* h, int32_t* ptr, int32_t* idx, double* val)
         std::copy(c->val.begin(), c->val.end(), val);
     }
     return mgbsetup_csr_sort_rows(c->rows, ptr, idx, val);
+}
+
+// Row sums of a CSR matrix exactly as `np.add.reduceat(data, indptr[nonempty])` (what scipy's `M.sum(axis=1)` runs) forms
+// them: first entry + pairwise_sum(rest), numpy's pairwise_sum being a plain loop below 8 terms, eight running sums up to 128,
+// and a split above (numpy/_core/src/umath/loops_utils.h.src).  The all-ones `uniform` subspace of a ladder is such a row sum.
+static double np_pairwise_sum(const double* a, int64_t n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+int mgbsetup_csr_row_sums(int64_t rows, const int32_t* ptr, const double* val, double* out) {
+    if (rows < 0 || (rows > 0 && (!ptr || !out))) return 1;
+    for (int64_t i = 0; i < rows; ++i) {
+        const int64_t lo = ptr[i], n = ptr[i + 1] - lo;
+        out[i] = n == 0 ? 0.0 : val[lo] + np_pairwise_sum(val + lo + 1, n - 1);
+    }
+    return 0;
 }
 
 // The whole ladder in one call: product k+1 is formed while product k is copied out and sorted on a second thread (both only

@@ -267,7 +267,10 @@ def _compose_R(subspaces: Dict[str, List[Any]], refine: Dict[str, List[Any]]):
             elif _is_identity(rfp[l]):
                 ops.append(_as_op(S))
             elif sp.issparse(S) and S.shape[1] == 1 and S.nnz == S.shape[0] and np.all(S.data == 1.0) and sp.issparse(rfp[l]):
-                ops.append(_as_op(sp.csr_matrix(np.asarray(rfp[l].sum(axis=1)).reshape(-1, 1))))
+                rs = _setup_native.csr_row_sums(rfp[l]) if sp.isspmatrix_csr(rfp[l]) or getattr(rfp[l], "format", "") == "csr" else None
+                if rs is None:
+                    rs = np.asarray(rfp[l].sum(axis=1)).ravel()
+                ops.append(_as_op(sp.csr_matrix(rs.reshape(-1, 1))))
             else:
                 ops.append(_as_op(_matmat(rfp[l], S)))
         out[X] = ops

@@ -332,6 +332,11 @@ def test_native_setup_helpers_are_bitwise_their_python_twins():
                 a, b = sp.csr_matrix(a), sp.csr_matrix(b)
                 assert a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
                 assert np.array_equal(a.data, b.data)
+    # row sums (the all-ones `uniform` subspace of a ladder) with numpy's own association: short rows, 8-accumulator rows, split rows
+    for n, dens in ((2000, 0.002), (500, 0.05), (300, 0.5), (50, 1.0)):
+        Mx = sp.random(n, 400, density=dens, random_state=n, format="csr")
+        Mx.data *= 10.0 ** rng.integers(-8, 8, Mx.nnz)
+        assert np.array_equal(nat.csr_row_sums(Mx), np.asarray(Mx.sum(axis=1)).ravel())
     # the chain alone against scipy, with an exact cancellation (dropped like scipy drops it) and an empty factor row
     A0 = sp.csr_matrix(np.array([[1.0, 1.0, 0.0], [2.0, 0.0, 0.5], [0.0, 0.0, 0.0]]))
     B1 = sp.csr_matrix(np.array([[1.0, 3.0], [-1.0, 4.0], [0.0, 0.0]]))
