@@ -46,10 +46,16 @@ class BlockDiag:
         return (self.p * self.N, self.q * self.N)
 
     def is_identity(self) -> bool:
-        if self.p != self.q:
-            return False
-        eye = np.eye(self.p)[:, :, None]
-        return bool(np.array_equal(self.data, np.broadcast_to(eye, self.data.shape)))
+        """Every block the identity?  Answered once per object (the blocks are not modified after construction)."""
+        cached = self.__dict__.get("_identity")
+        if cached is None:
+            if self.p != self.q:
+                cached = False
+            else:
+                eye = np.eye(self.p)[:, :, None]
+                cached = bool(np.array_equal(self.data, np.broadcast_to(eye, self.data.shape)))
+            self.__dict__["_identity"] = cached
+        return cached
 
     def to_sparse(self) -> sp.csr_matrix:
         """Sparse image (reference: src/BlockMatrices.jl:690-710, zeros dropped)."""
