@@ -40,6 +40,7 @@ def _classical_strength(A: sp.csr_matrix, theta: float) -> sp.csr_matrix:
     np.maximum.at(rowmax, rows, absd)
     keep = offdiag & (absd >= theta * rowmax[rows]) & (absd > 0)
     S = sp.csr_matrix((np.ones(keep.sum()), (rows[keep], indices[keep])), shape=(n, n))
+    S.strong_mask = keep           # the same information per stored entry of A (in A's storage order): _direct_interpolation reads it
     return S
 
 
@@ -204,8 +205,12 @@ def _direct_interpolation(A: sp.csr_matrix, S: sp.csr_matrix, is_c: np.ndarray) 
     nc = int(is_c.sum())
     Ap, Aj, Ax = A.indptr, A.indices.astype(np.int64), A.data
     row = np.repeat(np.arange(n, dtype=np.int64), np.diff(Ap))
-    Sb = sp.csr_matrix(S).astype(bool).tocoo()
-    in_S = np.isin(row * n + Aj, Sb.row.astype(np.int64) * n + Sb.col.astype(np.int64))
+    mask = getattr(S, "strong_mask", None)
+    if mask is not None and mask.shape == Ax.shape:
+        in_S = mask                # S was cut out of this very A by _classical_strength: its mask over A's entries
+    else:
+        Sb = sp.csr_matrix(S).astype(bool).tocoo()
+        in_S = np.isin(row * n + Aj, Sb.row.astype(np.int64) * n + Sb.col.astype(np.int64))
     offd = Aj != row
     neg = Ax < 0
     strong_c = offd & is_c[Aj] & in_S
