@@ -7,6 +7,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <thread>
 #include <utility>
@@ -126,16 +127,93 @@ struct Chain {
     int64_t rows = 0, cols = 0;
     std::vector<int32_t> ptr, idx;
     std::vector<double> val;
+    // Rows of the first operand that are identical entry for entry (the broken P2 nodes that share a mesh node carry the same
+    // row of the bridge) stay identical in every product of the chain: the products are formed on the DISTINCT rows only, in
+    // order of first occurrence, and written out through this map -- the same bits for 43 % of the work at L = 9.
+    std::shared_ptr<std::vector<int32_t>> rowmap;      // empty: the stored rows are the rows
+    int64_t full_rows = 0;
 };
+
+// (hash of a row's entries, row) pairs sorted; equal rows are verified entry for entry before they share a representative
+static void distinct_rows(const Chain& A, std::vector<int32_t>& rep_of_row, std::vector<int32_t>& reps) {
+    const int64_t n = A.rows;
+    std::vector<std::pair<uint64_t, int32_t>> key((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t h = 1469598103934665603ull;
+        for (int32_t q = A.ptr[i]; q < A.ptr[i + 1]; ++q) {
+            uint64_t bits;
+            std::memcpy(&bits, &A.val[q], sizeof(bits));
+            h ^= (uint64_t)(uint32_t)A.idx[q] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+            h ^= bits + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+        }
+        key[(size_t)i] = {h, (int32_t)i};
+    }
+    std::sort(key.begin(), key.end());
+    auto same = [&](int32_t a, int32_t b) {
+        const int32_t la = A.ptr[a + 1] - A.ptr[a];
+        if (la != A.ptr[b + 1] - A.ptr[b]) return false;
+        for (int32_t t = 0; t < la; ++t) {
+            if (A.idx[A.ptr[a] + t] != A.idx[A.ptr[b] + t]) return false;
+            if (std::memcmp(&A.val[A.ptr[a] + t], &A.val[A.ptr[b] + t], sizeof(double)) != 0) return false;
+        }
+        return true;
+    };
+    std::vector<int32_t> first((size_t)n);              // smallest row index identical to row i
+    size_t i = 0;
+    while (i < key.size()) {
+        size_t j = i;
+        while (j < key.size() && key[j].first == key[i].first) ++j;
+        // inside a run of equal hashes (sorted by row): every row takes the first earlier row it equals
+        for (size_t a = i; a < j; ++a) {
+            int32_t r = key[a].second;
+            first[(size_t)r] = r;
+            for (size_t b = i; b < a; ++b)
+                if (first[(size_t)key[b].second] == key[b].second && same(key[b].second, r)) { first[(size_t)r] = key[b].second; break; }
+        }
+        i = j;
+    }
+    rep_of_row.assign((size_t)n, -1);
+    reps.clear();
+    for (int64_t r = 0; r < n; ++r)
+        if (first[(size_t)r] == r) { rep_of_row[(size_t)r] = (int32_t)reps.size(); reps.push_back((int32_t)r); }
+    for (int64_t r = 0; r < n; ++r) rep_of_row[(size_t)r] = rep_of_row[(size_t)first[(size_t)r]];
+}
 }  // namespace
+
+// stored entries of the product as the caller sees it (all rows, not only the distinct ones)
+static int64_t full_nnz(const Chain& c) {
+    if (!c.rowmap) return (int64_t)c.idx.size();
+    int64_t n = 0;
+    for (int32_t r : *c.rowmap) n += c.ptr[(size_t)r + 1] - c.ptr[(size_t)r];
+    return n;
+}
 
 void* mgbsetup_chain_create(int64_t rows, int64_t cols, const int32_t* ptr, const int32_t* idx, const double* val) {
     if (rows < 0 || cols < 0 || !ptr) return nullptr;
     Chain* c = new Chain();
     c->rows = rows; c->cols = cols;
+    c->full_rows = rows;
     c->ptr.assign(ptr, ptr + rows + 1);
     const int64_t nnz = ptr[rows];
     if (nnz > 0) { c->idx.assign(idx, idx + nnz); c->val.assign(val, val + nnz); }
+    const char* env_min = std::getenv("MGB_SETUP_DISTINCT_MIN_ROWS");       // tests lower it to reach this path on small meshes
+    if (rows >= (env_min ? std::atoll(env_min) : 100000ll)) {   // large first operand: keep its distinct rows only, if that is a real saving
+        std::vector<int32_t> rep_of_row, reps;
+        distinct_rows(*c, rep_of_row, reps);
+        if ((int64_t)reps.size() * 4 <= rows * 3) {
+            Chain u;
+            u.rows = (int64_t)reps.size(); u.cols = cols; u.full_rows = rows;
+            u.ptr.assign(reps.size() + 1, 0);
+            for (size_t t = 0; t < reps.size(); ++t) {
+                const int32_t r = reps[t];
+                u.idx.insert(u.idx.end(), c->idx.begin() + c->ptr[r], c->idx.begin() + c->ptr[r + 1]);
+                u.val.insert(u.val.end(), c->val.begin() + c->ptr[r], c->val.begin() + c->ptr[r + 1]);
+                u.ptr[t + 1] = (int32_t)u.idx.size();
+            }
+            u.rowmap = std::make_shared<std::vector<int32_t>>(std::move(rep_of_row));
+            *c = std::move(u);
+        }
+    }
     return c;
 }
 
@@ -146,6 +224,7 @@ static bool chain_product(const Chain& A, int64_t bcols, const int32_t* Bp, cons
     std::vector<int32_t> next((size_t)bcols, -1);
     std::vector<double> sums((size_t)bcols, 0.0);
     out.rows = A.rows; out.cols = bcols;
+    out.rowmap = A.rowmap; out.full_rows = A.full_rows;
     out.ptr.assign((size_t)A.rows + 1, 0);
     out.idx.clear(); out.val.clear();
     {   // candidates per row bound the product: reserve once (untouched pages cost nothing), never reallocate
@@ -186,15 +265,31 @@ int64_t mgbsetup_chain_multiply(void* h, int64_t brows, int64_t bcols, const int
     Chain out;
     if (!chain_product(*c, bcols, Bp, Bj, Bx, out)) return -2;
     *c = std::move(out);
-    return (int64_t)c->idx.size();
+    return full_nnz(*c);
 }
 
-int64_t mgbsetup_chain_nnz(void* h) { return h ? (int64_t)static_cast<Chain*>(h)->idx.size() : -1; }
+int64_t mgbsetup_chain_nnz(void* h) { return h ? full_nnz(*static_cast<Chain*>(h)) : -1; }
 
 // The current product with sorted rows into ptr[rows + 1], idx[nnz], val[nnz] (caller-owned).
 int mgbsetup_chain_emit_sorted(void* h, int32_t* ptr, int32_t* idx, double* val) {
     Chain* c = static_cast<Chain*>(h);
     if (!c || !ptr) return 1;
+    if (c->rowmap) {                                    // sort the distinct rows once, then write every row through the map
+        Chain sorted = *c;
+        if (mgbsetup_csr_sort_rows(sorted.rows, sorted.ptr.data(), sorted.idx.data(), sorted.val.data()) != 0) return 1;
+        const std::vector<int32_t>& map = *c->rowmap;
+        int64_t w = 0;
+        ptr[0] = 0;
+        for (int64_t i = 0; i < c->full_rows; ++i) {
+            const int32_t r = map[(size_t)i];
+            const int32_t lo = sorted.ptr[r], len = sorted.ptr[r + 1] - lo;
+            std::copy(sorted.idx.begin() + lo, sorted.idx.begin() + lo + len, idx + w);
+            std::copy(sorted.val.begin() + lo, sorted.val.begin() + lo + len, val + w);
+            w += len;
+            ptr[i + 1] = (int32_t)w;
+        }
+        return 0;
+    }
     std::copy(c->ptr.begin(), c->ptr.end(), ptr);
     if (!c->idx.empty()) {
         std::copy(c->idx.begin(), c->idx.end(), idx);
@@ -256,10 +351,11 @@ int64_t mgbsetup_chain_run(void* h, int32_t nfac, const MgbSetupCsr* fac, MgbSet
         prods.emplace_back(new Chain());
         Chain* cur = prods.back().get();
         if (!chain_product(*prev, fac[k].cols, fac[k].ptr, fac[k].idx, fac[k].val, *cur)) { rc = -2; break; }
-        const int64_t nnz = (int64_t)cur->idx.size();
+        const int64_t nnz = full_nnz(*cur);
+        if (nnz >= (int64_t)INT32_MAX) { rc = -2; break; }
         MgbSetupOut* o = &outs[k];
         o->nnz = nnz;
-        o->ptr = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (size_t)(cur->rows + 1)));
+        o->ptr = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (size_t)(cur->full_rows + 1)));
         o->idx = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
         o->val = static_cast<double*>(std::malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
         if (!o->ptr || !o->idx || !o->val) { rc = -3; break; }

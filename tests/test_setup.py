@@ -1,5 +1,7 @@
 """Setup layer (CPU): element tables, operators, hierarchy shapes (reference tests:
 test/test_pure_p2.jl:28-51, test/test_tensorfem.jl:32-89, test/test_mixed_bc.jl)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -337,6 +339,28 @@ def test_native_setup_helpers_are_bitwise_their_python_twins():
         Mx = sp.random(n, 400, density=dens, random_state=n, format="csr")
         Mx.data *= 10.0 ** rng.integers(-8, 8, Mx.nnz)
         assert np.array_equal(nat.csr_row_sums(Mx), np.asarray(Mx.sum(axis=1)).ravel())
+    # rows of the first operand that repeat (broken nodes sharing a mesh node) are multiplied once and written out through a map
+    # (csrc/setup_host.cpp: distinct_rows; on by size, here forced): same ladders, bit for bit
+    os.environ["MGB_SETUP_DISTINCT_MIN_ROWS"] = "1"
+    try:
+        for g in (m.subdivide(m.fem2d_P2(), 4), m.subdivide(m.fem3d(k=1), 3)):
+            mg_c = m.amg(g)
+            nat._LIB, nat._TRIED = None, True
+            try:
+                mg_py = m.amg(g)
+            finally:
+                nat._TRIED = False
+            for sym in mg_c.R:
+                for a, b in zip(mg_c.R[sym], mg_py.R[sym]):
+                    a, b = sp.csr_matrix(a), sp.csr_matrix(b)
+                    assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data)
+        dup = sp.csr_matrix(np.array([[1.0, 2.0, 0.0], [0.0, 0.0, 3.0], [1.0, 2.0, 0.0], [1.0, 2.0, 0.0], [0.0, 0.0, 3.0], [0.0, 1.0, 0.0]]))
+        Bd = sp.random(3, 4, density=0.8, random_state=9, format="csr")
+        (got_d,) = nat.compose_chain(dup, [Bd])
+        want_d = (dup @ Bd); want_d.sort_indices()
+        assert np.array_equal(got_d.indptr, want_d.indptr) and np.array_equal(got_d.indices, want_d.indices) and np.array_equal(got_d.data, want_d.data)
+    finally:
+        del os.environ["MGB_SETUP_DISTINCT_MIN_ROWS"]
     # the chain alone against scipy, with an exact cancellation (dropped like scipy drops it) and an empty factor row
     A0 = sp.csr_matrix(np.array([[1.0, 1.0, 0.0], [2.0, 0.0, 0.5], [0.0, 0.0, 0.0]]))
     B1 = sp.csr_matrix(np.array([[1.0, 3.0], [-1.0, 4.0], [0.0, 0.0]]))
