@@ -163,3 +163,36 @@ def csr_row_sums(M):
     if lib.mgbsetup_csr_row_sums(M.shape[0], M.indptr.ctypes.data_as(ip), val.ctypes.data_as(dp), out.ctypes.data_as(dp)) != 0:
         return None
     return out
+
+
+def blockdiag(mats):
+    """scipy CSR block diagonal of CSR blocks (sorted rows assumed by the caller), or None when the library or a block does not
+    qualify.  The call runs without the interpreter lock: device.py builds the levels of an AMG on a thread pool."""
+    import scipy.sparse as sp
+    lib = _lib()
+    if lib is None or not mats or not all(_csr_ok(M) for M in mats):
+        return None
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    lib.mgbsetup_blockdiag.argtypes = [C.c_int32, C.POINTER(_Csr), ip, ip, dp]
+    rows = sum(M.shape[0] for M in mats)
+    cols = sum(M.shape[1] for M in mats)
+    nnz = sum(int(M.indptr[-1]) for M in mats)
+    if max(rows + 1, cols, nnz) >= 2**31 - 1:
+        return None
+    z32, z64 = np.zeros(1, dtype=np.int32), np.zeros(1)
+    blk = (_Csr * len(mats))()
+    keep = []
+    for k, M in enumerate(mats):
+        idx = M.indices if M.nnz else z32
+        val = M.data if M.nnz else z64
+        keep.extend([M.indptr, idx, val])
+        blk[k].rows, blk[k].cols = M.shape
+        blk[k].ptr, blk[k].idx, blk[k].val = M.indptr.ctypes.data_as(ip), idx.ctypes.data_as(ip), val.ctypes.data_as(dp)
+    indptr = np.empty(rows + 1, dtype=np.int32)
+    indices = np.empty(max(nnz, 1), dtype=np.int32)
+    data = np.empty(max(nnz, 1), dtype=np.float64)
+    if lib.mgbsetup_blockdiag(len(mats), blk, indptr.ctypes.data_as(ip), indices.ctypes.data_as(ip), data.ctypes.data_as(dp)) != 0:
+        return None
+    out = sp.csr_matrix((data[:nnz], indices[:nnz], indptr), shape=(rows, cols), copy=False)
+    out.has_sorted_indices = True
+    return out

@@ -134,10 +134,23 @@ struct Chain {
     int64_t full_rows = 0;
 };
 
-// (hash of a row's entries, row) pairs sorted; equal rows are verified entry for entry before they share a representative
+// Distinct rows by one pass over an open-addressing table keyed by a hash of the row's entries; a hit is verified entry for
+// entry (indices and the values' bits) before the row takes the earlier one as its representative.  rep_of_row[i] = index of
+// row i's representative among `reps` (the distinct rows in order of first occurrence).
 static void distinct_rows(const Chain& A, std::vector<int32_t>& rep_of_row, std::vector<int32_t>& reps) {
     const int64_t n = A.rows;
-    std::vector<std::pair<uint64_t, int32_t>> key((size_t)n);
+    size_t cap = 1;
+    while (cap < (size_t)(2 * n + 16)) cap <<= 1;
+    std::vector<int32_t> table(cap, -1);                // row index of the representative stored in a slot
+    auto same = [&](int32_t a, int32_t b) {
+        const int32_t la = A.ptr[a + 1] - A.ptr[a];
+        if (la != A.ptr[b + 1] - A.ptr[b]) return false;
+        if (la == 0) return true;
+        return std::memcmp(&A.idx[A.ptr[a]], &A.idx[A.ptr[b]], sizeof(int32_t) * (size_t)la) == 0 &&
+               std::memcmp(&A.val[A.ptr[a]], &A.val[A.ptr[b]], sizeof(double) * (size_t)la) == 0;
+    };
+    rep_of_row.assign((size_t)n, -1);
+    reps.clear();
     for (int64_t i = 0; i < n; ++i) {
         uint64_t h = 1469598103934665603ull;
         for (int32_t q = A.ptr[i]; q < A.ptr[i + 1]; ++q) {
@@ -146,37 +159,19 @@ static void distinct_rows(const Chain& A, std::vector<int32_t>& rep_of_row, std:
             h ^= (uint64_t)(uint32_t)A.idx[q] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
             h ^= bits + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
         }
-        key[(size_t)i] = {h, (int32_t)i};
-    }
-    std::sort(key.begin(), key.end());
-    auto same = [&](int32_t a, int32_t b) {
-        const int32_t la = A.ptr[a + 1] - A.ptr[a];
-        if (la != A.ptr[b + 1] - A.ptr[b]) return false;
-        for (int32_t t = 0; t < la; ++t) {
-            if (A.idx[A.ptr[a] + t] != A.idx[A.ptr[b] + t]) return false;
-            if (std::memcmp(&A.val[A.ptr[a] + t], &A.val[A.ptr[b] + t], sizeof(double)) != 0) return false;
+        size_t slot = (size_t)(h * 0x9e3779b97f4a7c15ull) & (cap - 1);
+        while (true) {
+            const int32_t r = table[slot];
+            if (r < 0) {                                // new distinct row
+                table[slot] = (int32_t)i;
+                rep_of_row[(size_t)i] = (int32_t)reps.size();
+                reps.push_back((int32_t)i);
+                break;
+            }
+            if (same(r, (int32_t)i)) { rep_of_row[(size_t)i] = rep_of_row[(size_t)r]; break; }
+            slot = (slot + 1) & (cap - 1);
         }
-        return true;
-    };
-    std::vector<int32_t> first((size_t)n);              // smallest row index identical to row i
-    size_t i = 0;
-    while (i < key.size()) {
-        size_t j = i;
-        while (j < key.size() && key[j].first == key[i].first) ++j;
-        // inside a run of equal hashes (sorted by row): every row takes the first earlier row it equals
-        for (size_t a = i; a < j; ++a) {
-            int32_t r = key[a].second;
-            first[(size_t)r] = r;
-            for (size_t b = i; b < a; ++b)
-                if (first[(size_t)key[b].second] == key[b].second && same(key[b].second, r)) { first[(size_t)r] = key[b].second; break; }
-        }
-        i = j;
     }
-    rep_of_row.assign((size_t)n, -1);
-    reps.clear();
-    for (int64_t r = 0; r < n; ++r)
-        if (first[(size_t)r] == r) { rep_of_row[(size_t)r] = (int32_t)reps.size(); reps.push_back((int32_t)r); }
-    for (int64_t r = 0; r < n; ++r) rep_of_row[(size_t)r] = rep_of_row[(size_t)first[(size_t)r]];
 }
 }  // namespace
 
@@ -331,11 +326,30 @@ int mgbsetup_csr_row_sums(int64_t rows, const int32_t* ptr, const double* val, d
     return 0;
 }
 
+struct MgbSetupCsr { int64_t rows, cols; const int32_t* ptr; const int32_t* idx; const double* val; };
+struct MgbSetupOut { int64_t nnz; int32_t* ptr; int32_t* idx; double* val; };
+
+// Block-diagonal concatenation of CSR matrices (AMG.R_fine = blockdiag of the state variables' prolongators,
+// src/multigrid.jl:491) into caller-owned arrays: row pointers shifted by the entries before, columns by the columns before.
+int mgbsetup_blockdiag(int32_t nblocks, const MgbSetupCsr* blk, int32_t* ptr, int32_t* idx, double* val) {
+    if (nblocks < 0 || (nblocks > 0 && (!blk || !ptr))) return 1;
+    int64_t r = 0, nz = 0, c0 = 0;
+    ptr[0] = 0;
+    for (int32_t b = 0; b < nblocks; ++b) {
+        const MgbSetupCsr& B = blk[b];
+        const int64_t bn = B.ptr[B.rows];
+        if (nz + bn >= (int64_t)INT32_MAX || c0 + B.cols >= (int64_t)INT32_MAX) return 2;
+        for (int64_t i = 0; i < B.rows; ++i) ptr[r + i + 1] = (int32_t)(nz + B.ptr[i + 1]);
+        for (int64_t q = 0; q < bn; ++q) idx[nz + q] = (int32_t)(c0 + B.idx[q]);
+        if (bn > 0) std::memcpy(val + nz, B.val, sizeof(double) * (size_t)bn);
+        r += B.rows; nz += bn; c0 += B.cols;
+    }
+    return 0;
+}
+
 // The whole ladder in one call: product k+1 is formed while product k is copied out and sorted on a second thread (both only
 // read product k).  outs[k] receives malloc'ed arrays (ptr: rows + 1, idx / val: nnz[k]) that the caller releases with
 // mgbsetup_free.  Returns 0, or the negative code of mgbsetup_chain_multiply.
-struct MgbSetupCsr { int64_t rows, cols; const int32_t* ptr; const int32_t* idx; const double* val; };
-struct MgbSetupOut { int64_t nnz; int32_t* ptr; int32_t* idx; double* val; };
 
 void mgbsetup_free(void* p) { std::free(p); }
 

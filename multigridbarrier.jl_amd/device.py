@@ -355,6 +355,8 @@ class DeviceProblem:
         d.L = L
         csr = (_CSR * L)()
         self.level_sizes = []
+        if hasattr(M.R_fine, "realize"):
+            M.R_fine.realize()           # block-diagonal prolongators of all levels at once (multigrid.LazyLevels)
         for l, R in enumerate(M.R_fine):
             Rs = sp.csr_matrix(R)
             Rs.sum_duplicates()

@@ -387,6 +387,9 @@ def _blockdiag(mats):
         for m in mats:
             if not m.has_sorted_indices:
                 m.sort_indices()
+        native = _setup_native.blockdiag(mats)       # the same concatenation in C++, without the interpreter lock
+        if native is not None:
+            return native
         nnz0 = np.cumsum([0] + [m.nnz for m in mats])
         col0 = np.cumsum([0] + [m.shape[1] for m in mats])
         rows = sum(m.shape[0] for m in mats)
@@ -426,6 +429,18 @@ class LazyLevels(_SequenceABC):
 
     def __len__(self) -> int:
         return len(self._items)
+
+    def realize(self, workers: int = 8) -> None:
+        """Build every entry that has not been built yet, on a thread pool (the builders of the package release the interpreter
+        lock inside libmgbsetup.so; without the library this is the serial loop with extra steps)."""
+        todo = [j for j, done in enumerate(self._built) if not done]
+        if len(todo) > 1 and _setup_native.available():
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(workers, len(todo))) as pool:
+                list(pool.map(self.__getitem__, todo))
+        else:
+            for j in todo:
+                self[j]
 
     def __getitem__(self, i):
         if isinstance(i, slice):
