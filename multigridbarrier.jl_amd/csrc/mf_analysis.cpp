@@ -46,15 +46,33 @@ void parallel_for(int64_t count, const std::function<void(int64_t, int64_t, int)
 // on the thread count.  917 k pairs at L = 9: 70 ms -> 10 ms.
 void sort_pairs(std::vector<std::pair<uint64_t, int32_t>>& a) {
     const size_t n = a.size();
-    if (n < 100000 || analyze_threads() <= 1) { std::sort(a.begin(), a.end()); return; }
+    const int nt = analyze_threads();
+    if (n < 100000 || nt <= 1) { std::sort(a.begin(), a.end()); return; }
+    // histogram and scatter by contiguous chunks, one per thread: chunk t's elements of bucket b land behind those of the chunks
+    // before it (a stable counting sort whatever the thread count), then every bucket is sorted on its own
+    std::vector<size_t> cnt((size_t)nt * 256, 0);
+    parallel_for(nt, [&](int64_t t0, int64_t t1, int) {
+        for (int64_t t = t0; t < t1; ++t) {
+            size_t* c = cnt.data() + (size_t)t * 256;
+            for (size_t i = n * (size_t)t / (size_t)nt; i < n * (size_t)(t + 1) / (size_t)nt; ++i) c[a[i].first >> 56]++;
+        }
+    }, true);
     std::vector<size_t> start(257, 0);
-    for (size_t i = 0; i < n; ++i) start[(a[i].first >> 56) + 1]++;
-    for (int b = 0; b < 256; ++b) start[b + 1] += start[b];
-    std::vector<std::pair<uint64_t, int32_t>> tmp(n);
     {
-        std::vector<size_t> fill(start.begin(), start.end() - 1);
-        for (size_t i = 0; i < n; ++i) tmp[fill[a[i].first >> 56]++] = a[i];
+        size_t run = 0;
+        for (int b = 0; b < 256; ++b) {
+            start[b] = run;
+            for (int t = 0; t < nt; ++t) { const size_t c = cnt[(size_t)t * 256 + b]; cnt[(size_t)t * 256 + b] = run; run += c; }
+        }
+        start[256] = run;
     }
+    std::vector<std::pair<uint64_t, int32_t>> tmp(n);
+    parallel_for(nt, [&](int64_t t0, int64_t t1, int) {
+        for (int64_t t = t0; t < t1; ++t) {
+            size_t* pos = cnt.data() + (size_t)t * 256;
+            for (size_t i = n * (size_t)t / (size_t)nt; i < n * (size_t)(t + 1) / (size_t)nt; ++i) tmp[pos[a[i].first >> 56]++] = a[i];
+        }
+    }, true);
     parallel_for(256, [&](int64_t b0, int64_t b1, int) {
         for (int64_t b = b0; b < b1; ++b) std::sort(tmp.begin() + (long)start[b], tmp.begin() + (long)start[b + 1]);
     }, true);
@@ -187,20 +205,44 @@ struct Builder {
                     ++ea; ++eb;
                 }
             };
-            std::vector<int32_t> group;
-            size_t i = 0;
+            // a group never leaves a run of equal hashes and always starts at the run's first unassigned entry: cut the sorted
+            // array into chunks at run boundaries, group every chunk on its own thread, concatenate in chunk order
             std::vector<std::vector<int32_t>> groups;
-            while (i < keyed.size()) {
-                group.clear();
-                group.push_back(keyed[i].second);
-                size_t j = i + 1;
-                while (j < keyed.size() && keyed[j].first == keyed[i].first && group.size() < 16 &&
-                       same_nb(keyed[i].second, keyed[j].second)) {
-                    group.push_back(keyed[j].second);
-                    ++j;
+            {
+                const int nt = keyed.size() >= 100000 ? analyze_threads() : 1;
+                std::vector<size_t> cut((size_t)nt + 1, keyed.size());
+                cut[0] = 0;
+                for (int t = 1; t < nt; ++t) {
+                    size_t c = std::max(cut[(size_t)t - 1], keyed.size() * (size_t)t / (size_t)nt);
+                    while (c > 0 && c < keyed.size() && keyed[c].first == keyed[c - 1].first) ++c;
+                    cut[(size_t)t] = c;
                 }
-                groups.push_back(group);
-                i = j;
+                std::vector<std::vector<std::vector<int32_t>>> part((size_t)nt);
+                parallel_for(nt, [&](int64_t t0, int64_t t1, int) {
+                    std::vector<int32_t> group;
+                    for (int64_t t = t0; t < t1; ++t) {
+                        auto& out = part[(size_t)t];
+                        size_t i = cut[(size_t)t];
+                        const size_t end = cut[(size_t)t + 1];
+                        while (i < end) {
+                            group.clear();
+                            group.push_back(keyed[i].second);
+                            size_t j = i + 1;
+                            while (j < end && keyed[j].first == keyed[i].first && group.size() < 16 &&
+                                   same_nb(keyed[i].second, keyed[j].second)) {
+                                group.push_back(keyed[j].second);
+                                ++j;
+                            }
+                            out.push_back(group);
+                            i = j;
+                        }
+                    }
+                }, true);
+                size_t total = 0;
+                for (auto& pt : part) total += pt.size();
+                groups.reserve(total);
+                for (auto& pt : part)
+                    for (auto& g2 : pt) groups.push_back(std::move(g2));
             }
             sub(round, "grouping");
             // removal happens after grouping so that `removed` is stable during same_nb
