@@ -1026,6 +1026,7 @@ void mgbhip_problem::prepare_all() {
     static const bool off = [] { const char* e = getenv("MGBHIP_LAZY_PLANS"); return e && e[0] == '1'; }();
     if (off || dense || sharded() || levels.size() < 2) return;     // sharded levels order their collectives: stay lazy
     const int Ln = (int)levels.size();
+    const auto t_prep0 = std::chrono::steady_clock::now();
     std::vector<std::exception_ptr> errors((size_t)Ln);
     std::atomic<int> next{Ln - 1};
     auto worker = [&] {
@@ -1043,11 +1044,17 @@ void mgbhip_problem::prepare_all() {
             }
         }
     };
-    const int nthreads = std::min(Ln, 6);
+    // three workers: the finest level's chain (plan -> analysis on up to 16 host threads of its own -> direct map) is the
+    // critical path, 0.5-0.6 s at L = 9; the other levels' 0.8 s of host work fit beside it on two workers without taking its
+    // cores (first solve at L = 9 with 2 / 3 / 4 / 6 workers: 1.57 / 1.36 / 1.48 / 1.44 s)
+    const int nthreads = std::min(Ln, 3);
     std::vector<std::thread> pool;
     for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
     worker();
     for (auto& t : pool) t.join();
+    if (const char* dbg = getenv("MGBHIP_DEBUG"); dbg && atoi(dbg) >= 2)
+        fprintf(stderr, "[mgbhip] prepare_all: %d levels in %.3f s\n", Ln,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prep0).count());
     // A level that could not be prepared (its plan exceeds an index range, the device is out of memory) is left to the lazy
     // path: the solve may never visit it (levels 8 and 9 of the L = 9 ladder are not), and if it does the error is raised there.
     for (size_t l = 0; l < errors.size(); ++l) {
