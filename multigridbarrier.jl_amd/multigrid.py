@@ -430,6 +430,10 @@ class LazyLevels(_SequenceABC):
     def __len__(self) -> int:
         return len(self._items)
 
+    def __reduce__(self):
+        """Pickles as the plain list of its (built) entries: the builder is a closure."""
+        return (list, ([self[j] for j in range(len(self._items))],))
+
     def realize(self, workers: int = 8) -> None:
         """Build every entry that has not been built yet, on a thread pool (the builders of the package release the interpreter
         lock inside libmgbsetup.so; without the library this is the serial loop with extra steps)."""

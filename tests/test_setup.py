@@ -390,3 +390,22 @@ def test_upper_bound_product_is_bitwise_scipys():
     got = _matmat(A, B)
     assert got.nnz == 3 and np.array_equal(got.toarray(), np.array([[0.0, 7.0], [2.0, 6.0]]))
     assert abs(_matmat(sp.identity(4, format="csr"), sp.csr_matrix((4, 3))) - sp.csr_matrix((4, 3))).nnz == 0
+
+
+def test_lazy_levels_build_on_demand_and_pickle_as_lists():
+    """AMG.R_fine is built level by level when first read (the phase-I member of the pair is rarely read: multigrid.LazyLevels);
+    it behaves like the list it replaced -- len, negative indices, slices, iteration -- and a problem still pickles."""
+    import pickle
+    prob = m.assemble(m.amg(m.subdivide(m.fem2d_P2(), 2)), p=1.5)
+    Rf = prob.M[1].R_fine
+    assert not any(Rf._built) and len(Rf) == len(prob.M[0].R_fine)
+    last = Rf[-1]
+    assert Rf._built.count(True) == 1 and Rf[len(Rf) - 1] is last
+    assert [R.shape for R in Rf[1:3]] == [Rf[1].shape, Rf[2].shape]
+    with pytest.raises(IndexError):
+        Rf[len(Rf)]
+    assert sum(1 for _ in Rf) == len(Rf) and all(Rf._built)
+    q = pickle.loads(pickle.dumps(prob))
+    assert isinstance(q.M[1].R_fine, list)
+    for a, b in zip(Rf, q.M[1].R_fine):
+        assert abs(sp.csr_matrix(a) - sp.csr_matrix(b)).nnz == 0
