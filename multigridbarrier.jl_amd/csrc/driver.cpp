@@ -95,9 +95,10 @@ bool trial_values(NewtonCtx& C, double& ynext, double& gnorm_next, int32_t* move
     // "moved" stamp are finished by ONE launch that also stores them in the pinned block (no reduce / copy launches)
     const bool fused = !P->dense;
     P->eval_f01_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c, P->d_gn.p, P->sharded() ? P->d_gnpart.p : nullptr, fused);
+    const double seq = P->next_seq();
     launch_trial_finish(P->d_gn.p, C.m, P->d_scratch.p, fused ? P->d_partials.p : nullptr, elem_grid(P->p, P->N), P->d_scal.p,
-                        P->d_flag.p, P->pin.dev, st, P->own_mask(C.level));
-    MGB_HIP_CHECK(hipStreamSynchronize(st));
+                        P->d_flag.p, P->pin.dev, st, P->own_mask(C.level), seq);
+    P->wait_results(seq);
     P->pin.i[0] = P->pin.d[4] == (double)P->step_stamp ? 1 : 0;      // the stamp of the step kernel that formed this trial point
     if (P->sharded()) {              // value, |g|^2, non-finite count and the "moved" flag in one sum over ranks
         P->pin.d[1] = (double)P->pin.i[0];
@@ -218,10 +219,11 @@ NewtonResult newton(NewtonCtx& C, const mgbhip_options& opt, const Stop& stop, i
             P->trisolve_carried(C.level, P->d_nv.p);
             // pivot flags, direction statistics and lambda^2 = <g, n> in one round trip: the finishing launch stores them in
             // the pinned block and clears the solver's flags for the next factorization (no copy / memset launches)
+            const double seq = P->next_seq();
             launch_dir_finish(P->d_nv.p, P->d_g.p, C.m, P->d_scratch.p, P->d_scal.p, L.solver.status_flags_rw(), P->pin.dev, st,
-                              P->own_mask(C.level));
+                              P->own_mask(C.level), seq);
             L.solver.flags_cleared();
-            MGB_HIP_CHECK(hipStreamSynchronize(st));
+            P->wait_results(seq);
             P->pin.i[1] = P->pin.d[5] != 0.0 ? 1 : 0;
             leaf_flag |= P->pin.d[6] != 0.0 ? 1 : 0;        // the condensed leaves are not re-formed by a refactorization: their flag sticks
             P->pin.i[2] = leaf_flag;

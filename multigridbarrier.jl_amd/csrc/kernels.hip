@@ -863,6 +863,7 @@ struct FinishParams {
     int32_t nints, ints_out, reset;
     double* host;
     int32_t host_lo, host_n;
+    double seq;                  // != 0: written to host[15] after the results (system-scope fence in between): the host polls it
 };
 __global__ __launch_bounds__(256) void finish_kernel(const FinishParams P) {
     __shared__ double red[256];
@@ -894,6 +895,13 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishParams P) {
         if (tid >= P.ints_out && tid < P.ints_out + P.nints) mine = true;
         if (mine) P.out[tid] = res[tid];
         if (P.host && tid >= P.host_lo && tid < P.host_lo + P.host_n) P.host[tid] = mine ? res[tid] : P.out[tid];
+    }
+    if (P.host && P.seq != 0.0) {
+        __threadfence_system();                      // this thread's result stores are visible to the host ...
+        __syncthreads();                             // ... for every writing thread, before the stamp
+        if (tid == 0) {
+            __hip_atomic_store(P.host + 15, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1805,7 +1813,7 @@ void launch_dir_stats(const double* v, const double* g, int64_t n, double* scrat
 // scal[5], scal[6] = the solver's status flags (read AND cleared: the next factorization / condensing f2 finds them zero
 // without a memset launch); scal[2..7) also lands in the pinned host block `host` (same indices).
 void launch_dir_finish(const double* v, const double* g, int64_t n, double* scratch, double* scal, int32_t* status2, double* host,
-                       hipStream_t st, const double* mask) {
+                       hipStream_t st, const double* mask, double seq) {
     const int nb = reduce_blocks(n);
     hipLaunchKernelGGL(dir_stats_kernel, dim3(nb), dim3(256), 0, st, v, g, n, scratch, mask);
     FinishParams F{};
@@ -1816,13 +1824,14 @@ void launch_dir_finish(const double* v, const double* g, int64_t n, double* scra
     F.out = scal;
     F.ints = status2; F.nints = 2; F.ints_out = 5; F.reset = 1;
     F.host = host; F.host_lo = 2; F.host_n = 5;
+    F.seq = seq;
     launch_finish(F, st);
 }
 
 // One line-search trial's read-back: scal[0] = f0 (sum of the element kernel's workgroup partials), scal[2] = |g|^2,
 // scal[3] = non-finite count of g, scal[4] = the step kernel's "moved" stamp; scal[0..5) -> host.
 void launch_trial_finish(const double* g, int64_t n, double* scratch, const double* f0_partials, int64_t f0_count, double* scal,
-                         int32_t* moved, double* host, hipStream_t st, const double* mask) {
+                         int32_t* moved, double* host, hipStream_t st, const double* mask, double seq) {
     const int nb = reduce_blocks(n);
     hipLaunchKernelGGL(block_reduce_kernel<1>, dim3(nb), dim3(256), 0, st, g, (const double*)nullptr, n, scratch, mask);
     FinishParams F{};
@@ -1834,6 +1843,7 @@ void launch_trial_finish(const double* g, int64_t n, double* scratch, const doub
     F.out = scal;
     F.ints = moved; F.nints = 1; F.ints_out = 4; F.reset = 0;
     F.host = host; F.host_lo = 0; F.host_n = 5;
+    F.seq = seq;
     launch_finish(F, st);
 }
 

@@ -98,9 +98,9 @@ void launch_dot(const double* a, const double* b, int64_t n, double* scratch, do
 //   direction: scal[2] = sum v^2, [3] = non-finite count of v, [4] = g.v, [5], [6] = status2[0..1] (read, then cleared)
 //   trial:     scal[0] = sum of f0_partials (nullptr: scal[0] is already final), [2] = sum g^2, [3] = non-finite count, [4] = *moved
 void launch_dir_finish(const double* v, const double* g, int64_t n, double* scratch, double* scal, int32_t* status2, double* host,
-                       hipStream_t st, const double* mask = nullptr);
+                       hipStream_t st, const double* mask = nullptr, double seq = 0.0);
 void launch_trial_finish(const double* g, int64_t n, double* scratch, const double* f0_partials, int64_t f0_count, double* scal,
-                         int32_t* moved, double* host, hipStream_t st, const double* mask = nullptr);
+                         int32_t* moved, double* host, hipStream_t st, const double* mask = nullptr, double seq = 0.0);
 void launch_index_gather(const double* v, const int32_t* idx, int64_t cnt, double* out, hipStream_t st);     // out[i] = v[idx[i]]
 void launch_index_scatter(const double* in, const int32_t* idx, int64_t cnt, double* v, hipStream_t st);    // v[idx[i]] = in[i]
 int64_t reduce_scratch_doubles(int64_t n);

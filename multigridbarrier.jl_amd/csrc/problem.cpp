@@ -982,6 +982,24 @@ void mgbhip_problem::eval_f2(int level, const double* d_s, const double* d_zz, c
     cnt.f2++;
 }
 
+void mgbhip_problem::wait_results(double seq) {
+    static const bool poll = [] { const char* e = getenv("MGBHIP_NO_POLL"); return !(e && e[0] == '1'); }();
+    hipStream_t st = stream();
+    if (poll && seq != 0.0) {
+        volatile const double* stamp = pin.d + 15;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spins = 0;; ++spins) {
+            if (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(stamp), __ATOMIC_ACQUIRE) ==
+                *reinterpret_cast<const uint64_t*>(&seq))
+                return;
+            if ((spins & 1023) == 1023 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 1e-3)
+                break;                                   // a long kernel or an error: let the runtime wait (and report)
+        }
+    }
+    MGB_HIP_CHECK(hipStreamSynchronize(st));
+}
+
 void mgbhip_problem::ensure_analysis(int level) {
     Level& L = levels[level];
     if (L.solver.analyzed) return;

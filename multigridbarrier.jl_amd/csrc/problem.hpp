@@ -145,6 +145,12 @@ struct mgbhip_problem {
     void ensure_analysis(int level);
     void ensure_direct(int level);
     void prepare_all();
+    // Read-backs of the Newton loop: the finishing kernel stores its results in the pinned block and a sequence stamp behind them;
+    // wait_results spins on the stamp (the host sees the stores a few microseconds before the runtime reports the kernel
+    // complete: 1 650 waits per solve at L = 9) and falls back to hipStreamSynchronize after a millisecond or when polling is off.
+    double next_seq() { return ++result_seq; }
+    void wait_results(double seq);
+    double result_seq = 0.0;
     std::mutex shared_mutex;               // prepare_all: state of the problem (not of one level) touched while levels are planned side by side
     bool prepared = false;
     void ensure_plan_dense(int level);

@@ -84,3 +84,13 @@ def test_device_transpose_of_the_prolongators_is_bitwise_the_host_loop(tmp_path)
         z0, its0 = solve(tmp_path, "device_T", {})
         z1, its1 = solve(tmp_path, "host_T", {"MGBHIP_HOST_TRANSPOSE": "1"})
         assert np.array_equal(z0, z1) and its0 == its1
+
+
+def test_polled_read_backs_equal_the_synchronised_ones(tmp_path):
+    """The Newton loop's two read-backs per iteration (direction statistics, line-search trial) are awaited by polling a sequence
+    stamp that the finishing kernel stores behind its results in the pinned block (mgbhip_problem::wait_results; the runtime's
+    hipStreamSynchronize reports the kernel a few microseconds later: 1 650 waits per solve at L = 9).  MGBHIP_NO_POLL=1 waits
+    with hipStreamSynchronize: the same numbers, hence the same solve bit for bit."""
+    z0, its0 = _solve(tmp_path, "poll", {})
+    z1, its1 = _solve(tmp_path, "sync", {"MGBHIP_NO_POLL": "1"})
+    assert np.array_equal(z0, z1) and its0 == its1
