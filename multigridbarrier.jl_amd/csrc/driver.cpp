@@ -53,8 +53,7 @@ struct VecStats { double sumsq, bad; };
 VecStats vec_stats(mgbhip_problem* P, int level, const double* d_v, int64_t len) {
     hipStream_t st = P->stream();
     launch_vec_stats(d_v, len, P->d_scratch.p, P->d_scal.p + 2, st, P->own_mask(level));
-    MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 2, P->d_scal.p + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    P->read_scalars(2, 2);
     if (P->sharded()) P->allreduce_host(P->pin.d + 2, 2, 0);
     return VecStats{P->pin.d[2], P->pin.d[3]};
 }
@@ -62,8 +61,7 @@ VecStats vec_stats(mgbhip_problem* P, int level, const double* d_v, int64_t len)
 double dev_dot(mgbhip_problem* P, int level, const double* a, const double* b, int64_t len) {
     hipStream_t st = P->stream();
     launch_dot(a, b, len, P->d_scratch.p, P->d_scal.p + 4, st, P->own_mask(level));
-    MGB_HIP_CHECK(hipMemcpyAsync(P->pin.d + 4, P->d_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
-    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    P->read_scalars(4, 1);
     if (P->sharded()) P->allreduce_host(P->pin.d + 4, 1, 0);
     return P->pin.d[4];
 }

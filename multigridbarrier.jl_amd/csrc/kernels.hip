@@ -1812,6 +1812,22 @@ void launch_dir_stats(const double* v, const double* g, int64_t n, double* scrat
 // The Newton direction's read-back in one finishing launch: scal[2] = sum v^2, scal[3] = non-finite count, scal[4] = g.v,
 // scal[5], scal[6] = the solver's status flags (read AND cleared: the next factorization / condensing f2 finds them zero
 // without a memset launch); scal[2..7) also lands in the pinned host block `host` (same indices).
+// n <= 16 scalars of the device block to the pinned host block (through its device pointer) with the sequence stamp behind
+// them: what a hipMemcpyAsync + hipStreamSynchronize pair did with a runtime copy kernel (11 us) and the runtime's wait.
+__global__ void publish_kernel(const double* __restrict__ src, int n, double* __restrict__ host, double* __restrict__ stamp, double seq) {
+    const int tid = threadIdx.x;
+    if (tid < n) host[tid] = src[tid];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(stamp, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void launch_publish(const double* src, int n, double* host_block, int host_lo, double seq, hipStream_t st) {
+    // host_block: device pointer of the 16-double pinned block; the stamp always goes to its slot 15
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, st, src, n, host_block + host_lo, host_block + 15, seq);
+    MGB_HIP_CHECK(hipGetLastError());
+}
+
 void launch_dir_finish(const double* v, const double* g, int64_t n, double* scratch, double* scal, int32_t* status2, double* host,
                        hipStream_t st, const double* mask, double seq) {
     const int nb = reduce_blocks(n);

@@ -780,8 +780,7 @@ void mgbhip_problem::eval_f0_launch(int level, const double* d_s, const double* 
 double mgbhip_problem::eval_f0(int level, const double* d_s, const double* d_zz, const double* d_cc) {
     hipStream_t st = stream();
     eval_f0_launch(level, d_s, d_zz, d_cc);
-    MGB_HIP_CHECK(hipMemcpyAsync(pin.d, d_scal.p, sizeof(double), hipMemcpyDeviceToHost, st));
-    MGB_HIP_CHECK(hipStreamSynchronize(st));
+    read_scalars(0, 1);
     if (sharded()) allreduce_host(pin.d, 1, 0);
     return pin.d[0];
 }
@@ -998,6 +997,12 @@ void mgbhip_problem::wait_results(double seq) {
         }
     }
     MGB_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+void mgbhip_problem::read_scalars(int lo, int n) {
+    const double seq = next_seq();
+    launch_publish(d_scal.p + lo, n, pin.dev, lo, seq, stream());
+    wait_results(seq);
 }
 
 void mgbhip_problem::ensure_analysis(int level) {

@@ -150,6 +150,8 @@ struct mgbhip_problem {
     // complete: 1 650 waits per solve at L = 9) and falls back to hipStreamSynchronize after a millisecond or when polling is off.
     double next_seq() { return ++result_seq; }
     void wait_results(double seq);
+    // d_scal[lo .. lo + n) -> pin.d[lo .. lo + n), awaited (publish kernel + polled stamp)
+    void read_scalars(int lo, int n);
     double result_seq = 0.0;
     std::mutex shared_mutex;               // prepare_all: state of the problem (not of one level) touched while levels are planned side by side
     bool prepared = false;
