@@ -86,13 +86,27 @@ struct NewtonCtx {
 // F0, F1 and the gradient statistics are launched back to back and read with ONE
 // synchronisation (value, sum of squares, non-finite count, and the step kernel's "moved" flag):
 // evaluating F1 at a point F0 rejects only produces NaN/Inf that nobody reads.
-bool trial_values(NewtonCtx& C, double& ynext, double& gnorm_next, int32_t* moved = nullptr) {
+bool trial_values(NewtonCtx& C, double& ynext, double& gnorm_next, int32_t* moved = nullptr, const double* step = nullptr) {
     mgbhip_problem* P = C.P;
     hipStream_t st = P->stream();
+    // step != nullptr: the trial point x - (*step) n has not been formed yet.  On a selection level the element kernel forms it
+    // on the fly and the step kernel that materialises it (and raises the "moved" stamp) runs behind the evaluation: the first
+    // launch after the host's decision is the long one, and the host has submitted the rest before it ends.
+    const bool onfly = step && P->can_fuse_step(C.level);
+    if (step) {
+        ++P->step_stamp;
+        if (!onfly) launch_step(P->d_x.p, P->d_nv.p, *step, P->d_xn.p, C.m, P->d_flag.p, P->step_stamp, st);
+        P->touch();
+        if (onfly) { P->trial_x = P->d_x.p; P->trial_dir = P->d_nv.p; P->trial_alpha = *step; }
+    }
     // the element kernel leaves its workgroup partials of f0; their sum, |g|^2, the non-finite count and the step kernel's
     // "moved" stamp are finished by ONE launch that also stores them in the pinned block (no reduce / copy launches)
     const bool fused = !P->dense;
     P->eval_f01_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c, P->d_gn.p, P->sharded() ? P->d_gnpart.p : nullptr, fused);
+    if (onfly) {
+        P->trial_x = nullptr; P->trial_dir = nullptr;
+        launch_step(P->d_x.p, P->d_nv.p, *step, P->d_xn.p, C.m, P->d_flag.p, P->step_stamp, st);
+    }
     const double seq = P->next_seq();
     launch_trial_finish(P->d_gn.p, C.m, P->d_scratch.p, fused ? P->d_partials.p : nullptr, elem_grid(P->p, P->N), P->d_scal.p,
                         P->d_flag.p, P->pin.dev, st, P->own_mask(C.level), seq);
@@ -121,11 +135,9 @@ bool linesearch_backtracking(NewtonCtx& C, const mgbhip_options& opt, double y, 
     double s = 1.0;
     bool have = false;
     while (s > 0.0) {
-        launch_step(P->d_x.p, P->d_nv.p, s, P->d_xn.p, C.m, P->d_flag.p, ++P->step_stamp, st);
-        P->touch();
         double yn, gn;
         int32_t moved = 0;
-        if (trial_values(C, yn, gn, &moved)) {
+        if (trial_values(C, yn, gn, &moved, &s)) {
             have = true;
             ynext = yn;
             gnorm_next = gn;

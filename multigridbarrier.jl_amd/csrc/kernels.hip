@@ -37,7 +37,7 @@ __device__ __forceinline__ double z_at(const ElemParams& P, int64_t i) {
     double v = P.z0[i];
     if (P.zsel) {
         const int32_t c = P.zsel[i];
-        if (c >= 0) v += P.zs[c];
+        if (c >= 0) v += P.zx ? __builtin_fma(-P.zalpha, P.zx[c], P.zs[c]) : P.zs[c];      // the same fma as step_kernel
         if (P.zout) P.zout[i] = v;
     }
     return v;
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void step_kernel(const double* __restrict__ x,
     bool m = false;
     if (i < len) {
         const double xi = x[i];
-        const double v = xi - s * nn[i];
+        const double v = __builtin_fma(-s, nn[i], xi);       // one rounding (what the contraction of xi - s * nn[i] gave): z_at forms the same value on the fly
         xn[i] = v;
         m = (v != xi);
     }

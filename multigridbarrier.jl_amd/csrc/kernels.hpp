@@ -51,6 +51,10 @@ struct ElemParams {
     const int32_t* zsel;
     const double* zs;
     double* zout;                            // with zsel: the kernel also stores z0 + R s (the next evaluation at this point reads it)
+    // line-search trial on a selection level: s is the trial point x - alpha n formed on the fly, zs = x, zx = n (the step kernel
+    // that materialises it runs BEHIND this evaluation instead of in front of it, off the host round trip's critical path)
+    const double* zx;
+    double zalpha;
 };
 
 // Fine-level Newton systems: H of the default problem couples the p broken slack unknowns of an element (diagonal

@@ -742,6 +742,7 @@ ElemParams mgbhip_problem::base_params(int level, const double* d_s, const doubl
             // at this point (the Hessian at an accepted line-search trial reads it back instead of chaining two gathers)
             E.zsel = L.Rsel.p;
             E.zs = d_s;
+            if (trial_x) { E.zs = trial_x; E.zx = trial_dir; E.zalpha = trial_alpha; }      // d_s (the trial vector) is written behind this launch
             E.zout = d_zfull.p;
             zf_stamp = zstamp; zf_level = level; zf_s = d_s; zf_z = d_zz;
             goto prolonged;
@@ -1003,6 +1004,11 @@ void mgbhip_problem::read_scalars(int lo, int n) {
     const double seq = next_seq();
     launch_publish(d_scal.p + lo, n, pin.dev, lo, seq, stream());
     wait_results(seq);
+}
+
+bool mgbhip_problem::can_fuse_step(int level) const {
+    static const bool off = [] { const char* e = getenv("MGBHIP_NO_FUSED_STEP"); return e && e[0] == '1'; }();
+    return !off && !dense && !sharded() && levels[level].R_unit;
 }
 
 void mgbhip_problem::ensure_analysis(int level) {

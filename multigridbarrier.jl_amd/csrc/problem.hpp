@@ -150,6 +150,12 @@ struct mgbhip_problem {
     // complete: 1 650 waits per solve at L = 9) and falls back to hipStreamSynchronize after a millisecond or when polling is off.
     double next_seq() { return ++result_seq; }
     void wait_results(double seq);
+    // fused line-search step (driver.cpp: trial_values): while set, the next evaluation on a selection level reads its point as
+    // trial_x - trial_alpha * trial_dir instead of through the (not yet written) trial vector
+    const double* trial_x = nullptr;
+    const double* trial_dir = nullptr;
+    double trial_alpha = 0.0;
+    bool can_fuse_step(int level) const;
     // d_scal[lo .. lo + n) -> pin.d[lo .. lo + n), awaited (publish kernel + polled stamp)
     void read_scalars(int lo, int n);
     double result_seq = 0.0;

@@ -94,3 +94,14 @@ def test_polled_read_backs_equal_the_synchronised_ones(tmp_path):
     z0, its0 = _solve(tmp_path, "poll", {})
     z1, its1 = _solve(tmp_path, "sync", {"MGBHIP_NO_POLL": "1"})
     assert np.array_equal(z0, z1) and its0 == its1
+
+
+def test_fused_line_search_step_is_bitwise_the_step_launch(tmp_path):
+    """On selection levels a backtracking trial is evaluated at x - s n formed on the fly by the element kernel (the same fused
+    multiply-add the step kernel performs), and the step kernel that materialises the trial vector runs behind the evaluation:
+    the first launch after the host's decision is the long one.  MGBHIP_NO_FUSED_STEP=1 launches the step first, as before:
+    the same solve bit for bit."""
+    for solve in (_solve, _solve3d):
+        z0, its0 = solve(tmp_path, "fused", {})
+        z1, its1 = solve(tmp_path, "step_first", {"MGBHIP_NO_FUSED_STEP": "1"})
+        assert np.array_equal(z0, z1) and its0 == its1
