@@ -102,14 +102,25 @@ bool trial_values(NewtonCtx& C, double& ynext, double& gnorm_next, int32_t* move
     // the element kernel leaves its workgroup partials of f0; their sum, |g|^2, the non-finite count and the step kernel's
     // "moved" stamp are finished by ONE launch that also stores them in the pinned block (no reduce / copy launches)
     const bool fused = !P->dense;
+    static const bool fuse_restrict = [] { const char* e = getenv("MGBHIP_NO_FUSED_RESTRICT"); return !(e && e[0] == '1'); }();
+    P->trial_fuse = mgbhip_problem::TrialFuse();
+    if (fused && fuse_restrict) {           // restriction + |g|^2 partials (+ the deferred step) in one launch where the level allows it
+        P->trial_fuse.want = true;
+        if (onfly) {
+            P->trial_fuse.x = P->d_x.p; P->trial_fuse.n = P->d_nv.p; P->trial_fuse.s = *step; P->trial_fuse.xn = P->d_xn.p;
+            P->trial_fuse.moved = P->d_flag.p; P->trial_fuse.stamp = P->step_stamp;
+        }
+    }
     P->eval_f01_launch(C.level, P->d_xn.p, C.d_zJ, C.d_c, P->d_gn.p, P->sharded() ? P->d_gnpart.p : nullptr, fused);
+    const bool restrict_fused = P->trial_fuse.done;
+    P->trial_fuse.want = false;
     if (onfly) {
         P->trial_x = nullptr; P->trial_dir = nullptr;
-        launch_step(P->d_x.p, P->d_nv.p, *step, P->d_xn.p, C.m, P->d_flag.p, P->step_stamp, st);
+        if (!restrict_fused) launch_step(P->d_x.p, P->d_nv.p, *step, P->d_xn.p, C.m, P->d_flag.p, P->step_stamp, st);
     }
     const double seq = P->next_seq();
     launch_trial_finish(P->d_gn.p, C.m, P->d_scratch.p, fused ? P->d_partials.p : nullptr, elem_grid(P->p, P->N), P->d_scal.p,
-                        P->d_flag.p, P->pin.dev, st, P->own_mask(C.level), seq);
+                        P->d_flag.p, P->pin.dev, st, P->own_mask(C.level), seq, restrict_fused);
     P->wait_results(seq);
     P->pin.i[0] = P->pin.d[4] == (double)P->step_stamp ? 1 : 0;      // the stamp of the step kernel that formed this trial point
     if (P->sharded()) {              // value, |g|^2, non-finite count and the "moved" flag in one sum over ranks

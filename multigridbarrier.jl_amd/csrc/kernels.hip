@@ -817,6 +817,51 @@ __global__ __launch_bounds__(256) void block_reduce_kernel(const double* __restr
     }
 }
 
+// Line-search trial, everything behind the element kernel in ONE launch: the restriction g = R' ret (row gather, as
+// csr_matvec_row_kernel), the partial sums of |g|^2 and its non-finite count (the same grid-stride order and LDS tree as
+// block_reduce_kernel<1>: identical partials), and the step kernel's work -- xn = x - s n with its own fused multiply-add and
+// the "moved" stamp.  Three launches fewer per trial than restrict + block_reduce + step.
+__global__ __launch_bounds__(256) void restrict_trial_kernel(int64_t rows, const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                             const double* __restrict__ val, const double* __restrict__ ret,
+                                                             double* __restrict__ g, double* __restrict__ partials,
+                                                             const double* __restrict__ x, const double* __restrict__ nn, double s,
+                                                             double* __restrict__ xn, int32_t* __restrict__ moved, int32_t stamp) {
+    __shared__ double red[256];
+    __shared__ double red2[256];
+    __shared__ int any_moved;
+    const int tid = threadIdx.x;
+    if (tid == 0) any_moved = 0;
+    __syncthreads();
+    double ss = 0.0, bad = 0.0;
+    bool m = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < rows; i += (int64_t)gridDim.x * 256) {
+        double acc = 0.0;
+        for (int32_t q = ptr[i]; q < ptr[i + 1]; ++q) acc += val[q] * ret[col[q]];
+        g[i] = acc;
+        ss += acc * acc;
+        bad += isfinite(acc) ? 0.0 : 1.0;
+        if (xn) {
+            const double xi = x[i];
+            const double v = __builtin_fma(-s, nn[i], xi);
+            xn[i] = v;
+            m = m || (v != xi);
+        }
+    }
+    red[tid] = ss;
+    red2[tid] = bad;
+    if (m) any_moved = 1;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) { red[tid] += red[tid + off]; red2[tid] += red2[tid + off]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        partials[blockIdx.x] = red[0];
+        partials[gridDim.x + blockIdx.x] = red2[0];
+        if (any_moved) *moved = stamp;
+    }
+}
+
 // Newton direction statistics in one pass: sum v*v, count of non-finite v, and g.v (the same per-block partial sums
 // and trees as block_reduce_kernel<1> and <0>: identical values, two launches fewer per Newton iteration)
 __global__ __launch_bounds__(256) void dir_stats_kernel(const double* __restrict__ v, const double* __restrict__ g, int64_t n,
@@ -1847,9 +1892,9 @@ void launch_dir_finish(const double* v, const double* g, int64_t n, double* scra
 // One line-search trial's read-back: scal[0] = f0 (sum of the element kernel's workgroup partials), scal[2] = |g|^2,
 // scal[3] = non-finite count of g, scal[4] = the step kernel's "moved" stamp; scal[0..5) -> host.
 void launch_trial_finish(const double* g, int64_t n, double* scratch, const double* f0_partials, int64_t f0_count, double* scal,
-                         int32_t* moved, double* host, hipStream_t st, const double* mask, double seq) {
+                         int32_t* moved, double* host, hipStream_t st, const double* mask, double seq, bool partials_ready) {
     const int nb = reduce_blocks(n);
-    hipLaunchKernelGGL(block_reduce_kernel<1>, dim3(nb), dim3(256), 0, st, g, (const double*)nullptr, n, scratch, mask);
+    if (!partials_ready) hipLaunchKernelGGL(block_reduce_kernel<1>, dim3(nb), dim3(256), 0, st, g, (const double*)nullptr, n, scratch, mask);
     FinishParams F{};
     int nj = 0;
     if (f0_partials) F.job[nj++] = FinishJob{f0_partials, f0_count, 0};
@@ -1889,6 +1934,15 @@ void launch_csr_matvec(int64_t rows, const int32_t* ptr, const int32_t* col, con
 }
 
 int csr_chunks(int64_t max_row_len) { return (int)((max_row_len + CHUNK - 1) / CHUNK); }
+
+void launch_restrict_trial(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val, const double* ret, double* g,
+                            double* scratch, const double* x, const double* nn, double s, double* xn, int32_t* moved, int32_t stamp,
+                            hipStream_t st) {
+    if (rows == 0) return;
+    const int nb = reduce_blocks(rows);                      // the partial-sum layout launch_trial_finish reads
+    hipLaunchKernelGGL(restrict_trial_kernel, dim3(nb), dim3(256), 0, st, rows, ptr, col, val, ret, g, scratch, x, nn, s, xn, moved, stamp);
+    MGB_HIP_CHECK(hipGetLastError());
+}
 
 void launch_csr_matvec_chunked(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val,
                                const double* x, double* y, double* scratch, int nchunk, hipStream_t st) {

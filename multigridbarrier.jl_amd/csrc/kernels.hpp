@@ -101,11 +101,17 @@ void launch_dot(const double* a, const double* b, int64_t n, double* scratch, do
 // (device-visible pointer of a hipHostMalloc block; same slot indices as `scal`) -- no copy launch, no memset launch:
 //   direction: scal[2] = sum v^2, [3] = non-finite count of v, [4] = g.v, [5], [6] = status2[0..1] (read, then cleared)
 //   trial:     scal[0] = sum of f0_partials (nullptr: scal[0] is already final), [2] = sum g^2, [3] = non-finite count, [4] = *moved
+// restriction + |g|^2 partials (+ the line-search step when xn != nullptr) in one launch; scratch gets the partial sums in the layout
+// launch_trial_finish(partials_ready = true) reads
+void launch_restrict_trial(int64_t rows, const int32_t* ptr, const int32_t* col, const double* val, const double* ret, double* g,
+                            double* scratch, const double* x, const double* nn, double s, double* xn, int32_t* moved, int32_t stamp,
+                            hipStream_t st);
 void launch_publish(const double* src, int n, double* host_block, int host_lo, double seq, hipStream_t st);
 void launch_dir_finish(const double* v, const double* g, int64_t n, double* scratch, double* scal, int32_t* status2, double* host,
                        hipStream_t st, const double* mask = nullptr, double seq = 0.0);
 void launch_trial_finish(const double* g, int64_t n, double* scratch, const double* f0_partials, int64_t f0_count, double* scal,
-                         int32_t* moved, double* host, hipStream_t st, const double* mask = nullptr, double seq = 0.0);
+                         int32_t* moved, double* host, hipStream_t st, const double* mask = nullptr, double seq = 0.0,
+                         bool partials_ready = false);
 void launch_index_gather(const double* v, const int32_t* idx, int64_t cnt, double* out, hipStream_t st);     // out[i] = v[idx[i]]
 void launch_index_scatter(const double* in, const int32_t* idx, int64_t cnt, double* v, hipStream_t st);    // v[idx[i]] = in[i]
 int64_t reduce_scratch_doubles(int64_t n);

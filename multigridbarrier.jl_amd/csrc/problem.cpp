@@ -856,7 +856,13 @@ void mgbhip_problem::eval_f01_launch(int level, const double* d_s, const double*
     }
     {
         StageScope sc(ctx->timers, "restrict");
-        if (L.T_chunks > 0)
+        trial_fuse.done = false;
+        if (trial_fuse.want && L.T_chunks == 0 && !L.T_long && !sharded()) {
+            // line-search trial: restriction, |g|^2 partial sums and the step kernel's work in one launch (kernels.hip)
+            launch_restrict_trial(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, d_scratch.p, trial_fuse.x, trial_fuse.n, trial_fuse.s,
+                                  trial_fuse.xn, trial_fuse.moved, trial_fuse.stamp, st);
+            trial_fuse.done = true;
+        } else if (L.T_chunks > 0)
             launch_csr_matvec_chunked(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, d_tchunk.p, L.T_chunks, st);
         else
             launch_csr_matvec(L.m, L.Tptr.p, L.Tcol.p, L.Tval.p, d_ret.p, d_gout, false, L.T_long, st);

@@ -156,6 +156,10 @@ struct mgbhip_problem {
     const double* trial_dir = nullptr;
     double trial_alpha = 0.0;
     bool can_fuse_step(int level) const;
+    // trial_fuse.want: the caller (trial_values) asks eval_f01_launch to run restriction, |g|^2 partials and the line-search step
+    // (x, n, s -> xn, moved stamp) as ONE launch where the level allows it; .done reports that it happened
+    struct TrialFuse { bool want = false, done = false; const double* x = nullptr; const double* n = nullptr; double s = 0.0;
+                       double* xn = nullptr; int32_t* moved = nullptr; int32_t stamp = 0; } trial_fuse;
     // d_scal[lo .. lo + n) -> pin.d[lo .. lo + n), awaited (publish kernel + polled stamp)
     void read_scalars(int lo, int n);
     double result_seq = 0.0;

@@ -105,3 +105,14 @@ def test_fused_line_search_step_is_bitwise_the_step_launch(tmp_path):
         z0, its0 = solve(tmp_path, "fused", {})
         z1, its1 = solve(tmp_path, "step_first", {"MGBHIP_NO_FUSED_STEP": "1"})
         assert np.array_equal(z0, z1) and its0 == its1
+
+
+def test_fused_restriction_of_a_trial_is_bitwise_the_separate_launches(tmp_path):
+    """A line-search trial runs three launches behind the element kernel -- restriction R' v, the partial sums of |g|^2, the
+    step kernel -- as ONE (`restrict_trial_kernel`: the same row gathers, the same grid-stride partial sums and LDS tree, the same
+    fused multiply-add) on levels whose restriction is the row-parallel kernel.  MGBHIP_NO_FUSED_RESTRICT=1 keeps the separate
+    launches: the same solve bit for bit, on a 2-D and on a 3-D ladder."""
+    for solve in (_solve, _solve3d):
+        z0, its0 = solve(tmp_path, "fused_restrict", {})
+        z1, its1 = solve(tmp_path, "separate", {"MGBHIP_NO_FUSED_RESTRICT": "1"})
+        assert np.array_equal(z0, z1) and its0 == its1
